@@ -1,0 +1,163 @@
+/* tfrecomm.h - C-ABI of libtfrecomm_hip.so: the MI355X (gfx950) implementation of the
+ * SVD matrix-factorisation minibatch training step of jilljenn/TF-recomm.
+ *
+ * The reference has no native/FFI interface for this path: its boundary is the TensorFlow
+ * 1.x Python API.  Each entry point below names the reference call it stands in for
+ * (file:line into the reference tree); INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions across the boundary;
+ *   - return 0 (TFR_OK) or a negative tfr_status; tfr_last_error() is thread-local text;
+ *   - the library owns all device memory; host pointers are borrowed for the duration of
+ *     the call and never freed by the library; outputs are caller-allocated;
+ *   - one host thread drives one model; work is stream-ordered on the model's HIP stream;
+ *     any call with a non-NULL host output pointer synchronises that stream before it
+ *     returns; `_dev` entry points take device pointers, return without synchronising
+ *     and report id errors at the next synchronising call;
+ *   - ids are validated on the device (the reference relies on TensorFlow's CPU gather
+ *     raising on out-of-range ids): an out-of-range id makes the step a no-op for every
+ *     table and the next synchronising call returns TFR_ERR_OOB;
+ *   - there is NO CPU fallback: without a usable HIP device tfr_create fails.
+ */
+#ifndef TFRECOMM_H
+#define TFRECOMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFR_ABI_VERSION 1
+
+typedef struct tfr_model tfr_model;
+
+typedef enum {
+    TFR_OK = 0,
+    TFR_ERR_ARG = -1,     /* bad argument / unsupported shape */
+    TFR_ERR_OOB = -2,     /* user or item id outside [0, user_num) / [0, item_num) */
+    TFR_ERR_HIP = -3,     /* HIP runtime error (text in tfr_last_error) */
+    TFR_ERR_STATE = -4,   /* call not valid in this state (e.g. resident step before upload) */
+    TFR_ERR_NOMEM = -5
+} tfr_status;
+
+/* which-table ids for set/get/frozen.  Values 0..4 are the five trainables of
+ * ops.py:8-12,29-32; +8 / +16 select the Adam first / second moment slot of that table. */
+enum {
+    TFR_MU = 0,           /* bias_global   []      ops.py:8     */
+    TFR_BU = 1,           /* user_bias     [U]     ops.py:9-10  */
+    TFR_BI = 2,           /* item_bias     [I]     ops.py:11-12 */
+    TFR_P = 3,            /* user_features [U,D]   ops.py:29-30 */
+    TFR_Q = 4,            /* item_features [I,D]   ops.py:31-32 */
+    TFR_SLOT_M = 8,
+    TFR_SLOT_V = 16
+};
+
+enum { TFR_LOSS_MSE = 0, TFR_LOSS_NLL = 1 };       /* ops.py:124 (canonical) / ops.py:125-126 (fork) */
+enum { TFR_OPT_ADAM = 0, TFR_OPT_SGD = 1 };        /* ops.py:144,148 (canonical) / ops.py:145,149 (fork) */
+enum { TFR_ADAM_TF1 = 0, TFR_ADAM_LAZY = 1 };      /* dense-moment TF1 semantics / touched rows only */
+
+typedef struct tfr_opts {
+    int32_t loss;         /* TFR_LOSS_*                                                    */
+    int32_t item_abs;     /* 1: dot uses |item_features| (ops.py:44)                        */
+    int32_t reg_bias;     /* 1: regulariser also has the two bias l2 terms (ops.py:85-89)   */
+    int32_t optimizer;    /* TFR_OPT_*                                                     */
+    int32_t adam_mode;    /* TFR_ADAM_*                                                    */
+    int32_t device;       /* HIP device ordinal                                            */
+    float lr;             /* learning_rate (ops.py:118)                                    */
+    float reg;            /* reg = lambda  (ops.py:118,137)                                */
+    float beta1, beta2, eps;  /* tf.train.AdamOptimizer defaults 0.9, 0.999, 1e-8          */
+    int32_t reserved[5];  /* must be zero                                                  */
+} tfr_opts;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+/* ops.inference_svd(..., user_num, item_num, dim) variable creation, ops.py:6-12,29-32.
+ * Tables start at zero; the host side initialises and uploads them (tfr_set_table). */
+int tfr_create(tfr_model** out, int64_t user_num, int64_t item_num, int32_t dim, const tfr_opts* opts);
+int tfr_destroy(tfr_model* m);
+void tfr_default_opts(tfr_opts* opts);
+
+/* ---- variables: tf.Variable.load / .eval and tf.train.Saver (svd_train_val.py:54,197-198) */
+int tfr_set_table(tfr_model* m, int32_t which, const float* host, int64_t n);
+int tfr_get_table(tfr_model* m, int32_t which, float* host, int64_t n);
+/* var_list of Optimizer.minimize (ops.py:146-149; adaptive_test.py:28): bit (1<<TFR_x) set
+ * = table x receives no update. */
+int tfr_set_frozen(tfr_model* m, uint32_t mask);
+/* global_step (svd_train_val.py:48, ops.py:119-120) and the Adam beta-power accumulators. */
+int tfr_get_step(tfr_model* m, int64_t* step, float* beta1_power, float* beta2_power);
+int tfr_set_step(tfr_model* m, int64_t step, float beta1_power, float beta2_power);
+/* change lr / reg between steps (the reference rebuilds the graph for that; ops.py:118). */
+int tfr_set_hyper(tfr_model* m, float lr, float reg);
+
+/* ---- forward: sess.run([logits, infer], feed_dict) - svd_train_val.py:120-122; ops.py:13-14,37-47 */
+int tfr_forward(tfr_model* m, const int32_t* user, const int32_t* item, int64_t batch,
+                float* logits_out);
+/* device-side validation metric: sum_k (infer_k - rate_k)^2 and count of infer==rate
+ * (svd_train_val.py:144-149).  host id/rate pointers. */
+int tfr_eval(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
+             int64_t batch, double* sum_sq_err_out, int64_t* n_equal_out);
+
+/* ---- one minibatch: sess.run([train_op, logits, infer], feed_dict) - svd_train_val.py:66-72;
+ *      ops.py:81-89 (regulariser), ops.py:118-153 (loss, minimize).
+ *      logits_out = pre-update logits of this batch; loss_out = data term only
+ *      (ops.py:152-153); reg_out = regulariser value.  Any may be NULL. */
+int tfr_train_step(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
+                   int64_t batch, float* logits_out, float* loss_out, float* reg_out);
+
+/* ---- device-resident (user,item,rate) store: the feed of dataio.ShuffleIterator
+ *      (dataio.py:98-103,114-117) kept in HBM; the host still draws the ids. */
+int tfr_upload_triples(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
+                       int64_t n);
+/* ids[step*batch + k] index the store: nsteps minibatches in one call.  loss_out[nsteps]
+ * (data term per step) may be NULL (then the call does not synchronise). */
+int tfr_train_steps_resident(tfr_model* m, const int64_t* ids, int64_t batch, int32_t nsteps,
+                             float* loss_out);
+/* upload pre-drawn ids once, then run steps [first, first+nsteps) from them with no host
+ * data in the loop. */
+int tfr_stage_ids(tfr_model* m, const int64_t* ids, int64_t n);
+int tfr_train_steps_staged(tfr_model* m, int64_t first_step, int64_t batch, int32_t nsteps,
+                           float* loss_out);
+/* forward over store rows [lo, hi): logits_out[hi-lo] host, may be NULL */
+int tfr_forward_resident(tfr_model* m, int64_t lo, int64_t hi, float* logits_out);
+
+/* ---- device-pointer entry points (plumbing for torch tensors / sharded multi-GPU) ------- */
+int tfr_forward_dev(tfr_model* m, const int32_t* d_user, const int32_t* d_item, int64_t batch,
+                    float* d_logits);
+int tfr_train_step_dev(tfr_model* m, const int32_t* d_user, const int32_t* d_item,
+                       const float* d_rate, int64_t batch, float* d_logits /* may be NULL */);
+int tfr_table_devptr(tfr_model* m, int32_t which, void** ptr, int64_t* n);
+int tfr_set_stream(tfr_model* m, void* hip_stream);   /* NULL = the model's own stream */
+int tfr_get_stream(tfr_model* m, void** hip_stream);
+/* last step's device scalars {loss, reg, sum_g} without a host copy */
+int tfr_scalars_devptr(tfr_model* m, void** ptr);
+
+/* ---- index work of the backward, exposed for bit-exact checks: stable sort of batch
+ *      positions by row id (what tf.unique + unsorted_segment_sum's batch-order walk reduce
+ *      to).  side 0 = user ids, 1 = item ids.  Host pointers; outputs [batch]. */
+int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t batch,
+                      int32_t* sorted_ids_out, int32_t* sorted_pos_out);
+
+/* ---- per-kernel timing with HIP events on the model's stream (bench.py roofline) -------- */
+enum {
+    TFR_K_FORWARD = 0,        /* gather-dot forward (+ fused loss/grad when training)       */
+    TFR_K_SORT = 1,           /* key sorts of both id columns                               */
+    TFR_K_REDUCE_ITEM = 2,    /* deterministic segmented reduce, item side                  */
+    TFR_K_REDUCE_USER = 3,    /* deterministic segmented reduce (+ fused lazy Adam), user   */
+    TFR_K_APPLY = 4,          /* Adam / SGD apply kernels                                   */
+    TFR_K_FINALIZE = 5,       /* scalar reduction + bias_global update                      */
+    TFR_K_GATHER = 6,         /* resident-store triple gather                               */
+    TFR_K_COUNT = 8
+};
+int tfr_profile(tfr_model* m, int32_t enable);                 /* enable resets the counters */
+int tfr_profile_read(tfr_model* m, int32_t kernel, double* total_ms, int64_t* launches);
+
+/* ---- misc ------------------------------------------------------------------------------ */
+int tfr_sync(tfr_model* m);            /* drains the stream; reports deferred TFR_ERR_OOB   */
+const char* tfr_last_error(void);
+int tfr_version(void);
+int tfr_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFRECOMM_H */

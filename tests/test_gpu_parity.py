@@ -1,0 +1,382 @@
+"""GPU parity: the HIP path (through the C-ABI) against the float64 oracle and the committed
+golden vectors.  Tolerance: 1e-5 scale-relative for floating point (north_star), bit-exact
+for index work.  Run with ``-m gpu`` on the MI355X box; nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+import tfrecomm_amd as T
+from tfrecomm_amd import _lib as L
+from oracle import svd_oracle as so
+from tests.util import RTOL, assert_close, dup_heavy_ids, make_oracle, rand_tables, rel_err, TABLE_NAMES
+
+pytestmark = pytest.mark.gpu
+
+TIDS = (L.MU, L.BU, L.BI, L.P, L.Q)
+
+
+def model_from(U, I, D, tables, **kw):
+    frozen = kw.pop("frozen", 0)
+    m = T.SvdModel(U, I, D, **kw)
+    m.set_tables(tables["mu"], tables["bu"], tables["bi"], tables["P"], tables["Q"])
+    if frozen:
+        m.set_frozen(frozen)
+    return m
+
+
+# ------------------------------------------------------------------ forward
+@pytest.mark.parametrize("U,I,D,B", [(7, 5, 3, 4), (50, 40, 15, 64), (300, 200, 64, 257), (300, 200, 128, 512),
+                                     (64, 64, 5, 33), (100, 80, 20, 100), (30, 30, 4, 1), (30, 30, 8, 63),
+                                     (30, 30, 32, 65), (40, 40, 256, 129), (40, 40, 1, 10), (40, 40, 63, 70)])
+@pytest.mark.parametrize("item_abs", [False, True])
+def test_forward_matches_oracle(U, I, D, B, item_abs):
+    rs = np.random.RandomState(U * 1000 + D)
+    t = rand_tables(rs, U, I, D)
+    u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+    with model_from(U, I, D, t, item_abs=item_abs) as m:
+        got = m.forward(u, i)
+    want = make_oracle(U, I, D, t, item_abs=item_abs).forward(u, i)
+    assert got.dtype == np.float32 and got.shape == (B,)
+    assert_close(got, want, what="logits")
+
+
+def test_forward_golden(golden):
+    g = golden("svd_forward_grad.npz")
+    for key in sorted({k.split("/")[0] for k in g.files}):
+        U, I, D, B = (int(x[1:]) for x in key.split("_"))
+        t = {k: g["%s/%s" % (key, k)] for k in ("mu", "bu", "bi", "P", "Q")}
+        u, i = g[key + "/u"], g[key + "/i"]
+        for ia in (0, 1):
+            with model_from(U, I, D, t, item_abs=bool(ia)) as m:
+                got = m.forward(u, i)
+            assert_close(got, g["%s/mse_abs%d_rb0/logits" % (key, ia)], what=key)
+
+
+def test_forward_accepts_float64_id_columns():
+    # the reference's iterator yields float64 columns (dataio.py:103,117)
+    rs = np.random.RandomState(3)
+    t = rand_tables(rs, 20, 20, 16)
+    u, i = rs.randint(0, 20, 50), rs.randint(0, 20, 50)
+    with model_from(20, 20, 16, t) as m:
+        a = m.forward(u.astype(np.float64), i.astype(np.float64))
+        b = m.forward(u.astype(np.int32), i.astype(np.int64))
+        assert np.array_equal(a, b)
+        with pytest.raises(ValueError):
+            m.forward(u + 0.5, i)
+
+
+# ------------------------------------------------------------------ loss / grads via one SGD step
+@pytest.mark.parametrize("loss", ["mse", "nll"])
+@pytest.mark.parametrize("item_abs", [0, 1])
+@pytest.mark.parametrize("reg_bias", [0, 1])
+def test_loss_reg_and_gradients_golden(golden, loss, item_abs, reg_bias):
+    """loss / regulariser values, and the reduced gradients recovered from one SGD step with
+    lr=1 (var_new = var - grad), against the float64 golden gradients."""
+    g = golden("svd_forward_grad.npz")
+    for key in sorted({k.split("/")[0] for k in g.files}):
+        U, I, D, B = (int(x[1:]) for x in key.split("_"))
+        t = {k: g["%s/%s" % (key, k)] for k in ("mu", "bu", "bi", "P", "Q")}
+        u, i, r = g[key + "/u"], g[key + "/i"], g["%s/r_%s" % (key, loss)]
+        tag = "%s/%s_abs%d_rb%d" % (key, loss, item_abs, reg_bias)
+        with model_from(U, I, D, t, loss=loss, item_abs=bool(item_abs), reg_bias=bool(reg_bias),
+                        optimizer="sgd", lr=1.0, reg=0.05) as m:
+            logits, lossv, regv = m.train_step(u, i, r)
+            after = m.tables()
+        assert_close(logits, g[tag + "/logits"], what=tag + " logits")
+        assert_close(lossv, g[tag + "/loss"], what=tag + " loss")
+        assert_close(regv, g[tag + "/reg"], what=tag + " reg")
+        uq_u, uq_i = g[tag + "/uniq_u"], g[tag + "/uniq_i"]
+        gP = t["P"][uq_u].astype(np.float64) - after[L.P][uq_u]
+        gQ = t["Q"][uq_i].astype(np.float64) - after[L.Q][uq_i]
+        gbu = t["bu"][uq_u].astype(np.float64) - after[L.BU][uq_u]
+        gbi = t["bi"][uq_i].astype(np.float64) - after[L.BI][uq_i]
+        gmu = float(t["mu"]) - float(after[L.MU])
+        # recovered through an fp32 subtraction: tolerance relative to max(|var|,|grad|)
+        for got, want, var, name in ((gP, g[tag + "/gP"], t["P"], "gP"), (gQ, g[tag + "/gQ"], t["Q"], "gQ"),
+                                     (gbu, g[tag + "/gbu"], t["bu"], "gbu"), (gbi, g[tag + "/gbi"], t["bi"], "gbi")):
+            scale = max(np.abs(want).max(), np.abs(var).max())
+            assert np.abs(got - want).max() <= 4e-6 * scale, "%s %s" % (tag, name)
+        assert abs(gmu - float(g[tag + "/gmu"])) <= 4e-6 * max(1.0, abs(float(g[tag + "/gmu"])))
+        # rows not in the batch are untouched by SGD
+        mask = np.ones(U, bool); mask[uq_u] = False
+        assert np.array_equal(after[L.P][mask], t["P"][mask])
+
+
+# ------------------------------------------------------------------ trajectories
+def _check_tables(m, want_tables, tag, rtol):
+    got = m.tables()
+    for tid in TIDS:
+        assert_close(got[tid], want_tables[tid], rtol=rtol, what="%s table %s" % (tag, TABLE_NAMES[tid]))
+
+
+def test_trajectories_golden(golden):
+    g = golden("svd_trajectories.npz")
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) >= 6
+    from tests.golden.make_golden import TRAJ_CASES, NSTEPS
+    for name, U, I, D, B, kw in TRAJ_CASES:
+        kw = dict(kw)
+        frozen = kw.pop("frozen", 0)
+        t = {k: g["%s/init/%s" % (name, k)] for k in ("mu", "bu", "bi", "P", "Q")}
+        with model_from(U, I, D, t, frozen=frozen, **kw) as m:
+            for s in range(NSTEPS):
+                p = "%s/step%d/" % (name, s)
+                logits, lossv, regv = m.train_step(g[p + "u"], g[p + "i"], g[p + "r"])
+                # error accumulates over steps: allow 1e-5 per step taken
+                tol = RTOL * (s + 1)
+                assert_close(logits, g[p + "logits"], rtol=tol, what=p + "logits")
+                assert_close(lossv, g[p + "loss"], rtol=tol, what=p + "loss")
+                assert_close(regv, g[p + "reg"], rtol=tol, what=p + "reg")
+                want = {tid: g[p + TABLE_NAMES[tid]] for tid in TIDS}
+                _check_tables(m, want, p, tol)
+                if kw["optimizer"] == "adam":
+                    for tid in TIDS:
+                        # bias_global's gradient is sum_k g_k, a cancelling sum of B fp32 values:
+                        # its relative error is cond = sum|g| / |sum g| times the per-term 1e-7,
+                        # and v squares it.  Scale that one scalar's tolerance by cond.
+                        cond = 1.0
+                        if tid == L.MU:
+                            gk = so.dlogits(g[p + "logits"], g[p + "r"].astype(np.float64), kw["loss"])
+                            cond = max(1.0, float(np.abs(gk).sum() / max(abs(gk.sum()), 1e-30)))
+                        assert_close(m.get_table(tid | L.SLOT_M), g[p + TABLE_NAMES[tid] + "_m"], rtol=tol * cond, what=p + "m")
+                        assert_close(m.get_table(tid | L.SLOT_V), g[p + TABLE_NAMES[tid] + "_v"], rtol=2 * tol * cond, what=p + "v")
+            assert m.step == NSTEPS
+
+
+@pytest.mark.parametrize("opt,mode", [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")])
+@pytest.mark.parametrize("loss,item_abs,reg_bias", [("mse", 0, 0), ("nll", 1, 1)])
+@pytest.mark.parametrize("D", [15, 64, 128])
+def test_trajectory_vs_oracle_seeded(opt, mode, loss, item_abs, reg_bias, D):
+    """10 steps on seeded inputs against the float64 oracle run side by side."""
+    U, I, B = 500, 300, 700
+    rs = np.random.RandomState(D + 17)
+    t = rand_tables(rs, U, I, D)
+    kw = dict(loss=loss, item_abs=bool(item_abs), reg_bias=bool(reg_bias), optimizer=opt, adam_mode=mode,
+              lr=2e-3, reg=0.03)
+    orc = make_oracle(U, I, D, t, **kw)
+    with model_from(U, I, D, t, **kw) as m:
+        for s in range(10):
+            u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+            r = (rs.rand(B) < 0.5).astype(np.float32) if loss == "nll" else rs.randint(1, 6, B).astype(np.float32)
+            logits, lossv, regv = m.train_step(u, i, r)
+            wl, wloss, wreg = orc.train_step(u, i, r)
+            tol = RTOL * (s + 1)
+            assert_close(logits, wl, rtol=tol, what="step %d logits" % s)
+            assert_close(lossv, wloss, rtol=tol, what="step %d loss" % s)
+            assert_close(regv, wreg, rtol=tol, what="step %d reg" % s)
+        _check_tables(m, orc.tables(), "final", RTOL * 10)
+        # RMSE of the final model on a held-out batch (svd_train_val.py:149)
+        u, i = rs.randint(0, U, 1000), rs.randint(0, I, 1000)
+        r = rs.randint(1, 6, 1000).astype(np.float32)
+        got = so.rmse(r, so.head(m.forward(u, i).astype(np.float64), loss))
+        want = so.rmse(r, orc.infer(u, i))
+        assert abs(got - want) <= RTOL * want
+
+
+# ------------------------------------------------------------------ index work: bit-exact
+def test_sort_segments_bit_exact(golden):
+    g = golden("svd_segments.npz")
+    for key in sorted({k.split("/")[0] for k in g.files}):
+        n = int(key.split("_")[0][1:])
+        ids = g[key + "/ids"]
+        with T.SvdModel(n, n, 4) as m:
+            for side in (0, 1):
+                ks, ps = m.sort_segments(side, ids)
+                assert np.array_equal(ks, g[key + "/sorted_ids"]), key
+                assert np.array_equal(ps, g[key + "/sorted_pos"]), key
+        heads = np.flatnonzero(np.concatenate(([True], ks[1:] != ks[:-1])))
+        assert np.array_equal(np.concatenate((heads, [ks.size])), g[key + "/seg_start"])
+        # unique in first-occurrence order == ids at the sorted positions of each head, re-ordered
+        first = np.sort(ps[heads])
+        assert np.array_equal(ids[first], g[key + "/unique_first_occurrence"])
+
+
+def test_sort_large_random_matches_numpy():
+    rs = np.random.RandomState(5)
+    n, B = 10_000_000, 262144
+    ids = rs.randint(0, n, B).astype(np.int32)
+    with T.SvdModel(n, 16, 4, optimizer="sgd") as m:
+        ks, ps = m.sort_segments(0, ids)
+    want = np.argsort(ids, kind="stable").astype(np.int32)
+    assert np.array_equal(ps, want)
+    assert np.array_equal(ks, ids[want])
+
+
+# ------------------------------------------------------------------ determinism
+@pytest.mark.parametrize("opt,mode", [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")])
+def test_run_to_run_bit_identical(opt, mode):
+    U, I, D, B = 2000, 1500, 64, 5000
+    rs = np.random.RandomState(11)
+    t = rand_tables(rs, U, I, D)
+    batches = [(dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B), rs.randint(1, 6, B).astype(np.float32)) for _ in range(4)]
+    outs = []
+    for rep in range(2):
+        with model_from(U, I, D, t, optimizer=opt, adam_mode=mode) as m:
+            res = [m.train_step(*b) for b in batches]
+            outs.append((res, m.tables()))
+    for (la, lossa, rega), (lb, lossb, regb) in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(la, lb) and lossa == lossb and rega == regb
+    for tid in TIDS:
+        assert np.array_equal(outs[0][1][tid], outs[1][1][tid])
+
+
+# ------------------------------------------------------------------ edge cases
+def test_out_of_range_ids_raise_and_leave_state_untouched():
+    U, I, D = 50, 40, 16
+    rs = np.random.RandomState(2)
+    t = rand_tables(rs, U, I, D)
+    with model_from(U, I, D, t, optimizer="adam", adam_mode="tf1") as m:
+        u, i = rs.randint(0, U, 64).astype(np.int32), rs.randint(0, I, 64).astype(np.int32)
+        r = rs.randint(1, 6, 64).astype(np.float32)
+        for bad_u, bad_i in ((U, 0), (-1, 0), (0, I), (0, -5)):
+            uu, ii = u.copy(), i.copy()
+            uu[7], ii[9] = (bad_u if bad_u not in (0,) else uu[7]), (bad_i if bad_i not in (0,) else ii[9])
+            with pytest.raises(T.OutOfRangeError):
+                m.forward(uu, ii)
+            with pytest.raises(IndexError):
+                m.train_step(uu, ii, r)
+            assert m.step == 0
+            after = m.tables()
+            for tid, name in TABLE_NAMES.items():
+                assert np.array_equal(after[tid].reshape(-1), np.asarray(t[name]).reshape(-1)), name
+        m.train_step(u, i, r)          # still usable afterwards
+        assert m.step == 1
+
+
+@pytest.mark.parametrize("opt,mode", [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")])
+@pytest.mark.parametrize("B", [0, 1, 63, 64, 65])
+def test_ragged_and_empty_batches(opt, mode, B):
+    U, I, D = 30, 20, 20
+    rs = np.random.RandomState(B)
+    t = rand_tables(rs, U, I, D)
+    kw = dict(optimizer=opt, adam_mode=mode, lr=1e-2, reg=0.05)
+    orc = make_oracle(U, I, D, t, **kw)
+    with model_from(U, I, D, t, **kw) as m:
+        for s in range(2):
+            u, i = rs.randint(0, U, B).astype(np.int32), rs.randint(0, I, B).astype(np.int32)
+            r = rs.randint(1, 6, B).astype(np.float32)
+            logits, lossv, regv = m.train_step(u, i, r)
+            wl, wloss, wreg = orc.train_step(u, i, r)
+            assert logits.shape == (B,)
+            if B:
+                assert_close(logits, wl, rtol=2 * RTOL)
+                assert_close(lossv, wloss, rtol=2 * RTOL)
+                assert_close(regv, wreg, rtol=2 * RTOL)
+            else:
+                assert lossv == 0.0 and regv == 0.0
+        _check_tables(m, orc.tables(), "B=%d" % B, 2 * RTOL)
+        assert m.forward(np.zeros(0, np.int32), np.zeros(0, np.int32)).shape == (0,)
+
+
+def test_all_identical_ids_long_segment():
+    """one row with thousands of duplicates in the batch (worst case for the segmented reduce)"""
+    U, I, D, B = 10, 10, 64, 5000
+    rs = np.random.RandomState(8)
+    t = rand_tables(rs, U, I, D, scale=0.05)
+    kw = dict(optimizer="adam", adam_mode="lazy", lr=1e-3, reg=0.05)
+    orc = make_oracle(U, I, D, t, **kw)
+    u, i = np.full(B, 3, np.int32), np.full(B, 7, np.int32)
+    r = rs.randint(1, 6, B).astype(np.float32)
+    with model_from(U, I, D, t, **kw) as m:
+        logits, lossv, regv = m.train_step(u, i, r)
+        wl, wloss, wreg = orc.train_step(u, i, r)
+        assert_close(logits, wl)
+        assert_close(lossv, wloss)
+        assert_close(regv, wreg)
+        _check_tables(m, orc.tables(), "identical", RTOL)
+
+
+def test_frozen_tables_var_list():
+    """var_list=[user_bias, user_features] (adaptive_test.py:28): the other three never move."""
+    U, I, D, B = 60, 50, 20, 200
+    rs = np.random.RandomState(4)
+    t = rand_tables(rs, U, I, D)
+    frozen = (1 << L.MU) | (1 << L.BI) | (1 << L.Q)
+    for kw in (dict(optimizer="adam", adam_mode="tf1"), dict(optimizer="adam", adam_mode="lazy"), dict(optimizer="sgd")):
+        orc = make_oracle(U, I, D, t, frozen=frozen, **kw)
+        with model_from(U, I, D, t, frozen=frozen, **kw) as m:
+            for s in range(3):
+                u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+                r = rs.randint(1, 6, B).astype(np.float32)
+                m.train_step(u, i, r)
+                orc.train_step(u, i, r)
+            after = m.tables()
+            assert np.array_equal(after[L.Q], t["Q"]) and np.array_equal(after[L.BI], t["bi"])
+            assert float(after[L.MU]) == float(t["mu"])
+            assert not np.array_equal(after[L.P], t["P"])
+            _check_tables(m, orc.tables(), "frozen", 3 * RTOL)
+
+
+# ------------------------------------------------------------------ resident store / eval
+def test_resident_store_equals_host_fed_steps():
+    U, I, D, N, B, K = 300, 200, 64, 5000, 256, 6
+    rs = np.random.RandomState(21)
+    t = rand_tables(rs, U, I, D)
+    su, si = rs.randint(0, U, N).astype(np.int32), rs.randint(0, I, N).astype(np.int32)
+    sr = rs.randint(1, 6, N).astype(np.float32)
+    ids = rs.randint(0, N, (K, B))
+    kw = dict(optimizer="adam", adam_mode="lazy")
+    with model_from(U, I, D, t, **kw) as a, model_from(U, I, D, t, **kw) as b:
+        a.upload_triples(su, si, sr)
+        la = a.train_steps_resident(ids, B)
+        lb = [b.train_step(su[ids[k]], si[ids[k]], sr[ids[k]])[1] for k in range(K)]
+        assert np.array_equal(la, np.array(lb, np.float32))
+        for tid in TIDS:
+            assert np.array_equal(a.get_table(tid), b.get_table(tid))
+        # staged ids: same again, split in two calls
+        c = model_from(U, I, D, t, **kw)
+        c.upload_triples(su, si, sr)
+        c.stage_ids(ids)
+        c.train_steps_staged(0, B, 2)
+        lc = c.train_steps_staged(2, B, K - 2, want_loss=True)
+        assert np.array_equal(lc, la[2:])
+        assert np.array_equal(c.get_table(L.P), a.get_table(L.P))
+        assert np.array_equal(c.forward_resident(10, 500), a.forward(su[10:500], si[10:500]))
+        with pytest.raises(T.OutOfRangeError):
+            c.train_steps_resident(np.array([[N] * B]), B)
+        c.close()
+
+
+@pytest.mark.parametrize("loss", ["mse", "nll"])
+def test_eval_sse_and_accuracy(loss):
+    U, I, D, N = 200, 150, 15, 30001
+    rs = np.random.RandomState(6)
+    t = rand_tables(rs, U, I, D)
+    u, i = rs.randint(0, U, N), rs.randint(0, I, N)
+    r = (rs.rand(N) < 0.5).astype(np.float32) if loss == "nll" else rs.randint(1, 6, N).astype(np.float32)
+    orc = make_oracle(U, I, D, t, loss=loss)
+    with model_from(U, I, D, t, loss=loss) as m:
+        sse, neq = m.eval(u, i, r)
+    inf = orc.infer(u, i)
+    want_sse = float(np.sum((inf - r) ** 2))
+    if loss == "mse":
+        assert abs(sse - want_sse) <= RTOL * want_sse
+        assert abs(np.sqrt(sse / N) - so.rmse(r, inf)) <= RTOL * so.rmse(r, inf)
+    else:
+        # rounding of sigmoid(x) at exactly 0.5 can differ only where |x| < 1e-6
+        assert abs(neq - int(np.sum(inf == r))) <= 2
+        assert abs(sse - want_sse) <= 2
+
+
+# ------------------------------------------------------------------ full-size properties (C3-shaped forward)
+def test_forward_large_properties():
+    """BASELINE config 3 shape scaled to fit a test (D=128, B=262144, 2M x 200k rows):
+    permutation equivariance (bitwise), bias linearity, and a sampled oracle check."""
+    U, I, D, B = 2_000_000, 200_000, 128, 262144
+    rs = np.random.RandomState(9)
+    gen = np.random.default_rng(9)
+    P = gen.standard_normal((U, D), dtype=np.float32) * np.float32(0.1)
+    Q = gen.standard_normal((I, D), dtype=np.float32) * np.float32(0.1)
+    bu, bi = gen.standard_normal(U, dtype=np.float32), gen.standard_normal(I, dtype=np.float32)
+    u, i = rs.randint(0, U, B).astype(np.int32), rs.randint(0, I, B).astype(np.int32)
+    with T.SvdModel(U, I, D, optimizer="sgd") as m:
+        m.set_tables(0.25, bu, bi, P, Q)
+        a = m.forward(u, i)
+        perm = rs.permutation(B)
+        b = m.forward(u[perm], i[perm])
+        assert np.array_equal(a[perm], b)                      # per-rating result independent of batch position
+        m.set_table(L.MU, np.float32(1.25))
+        c = m.forward(u, i)
+        assert np.abs((c - a) - 1.0).max() <= 1e-5             # logits are affine in bias_global
+    sel = rs.randint(0, B, 4096)
+    want = (P[u[sel]].astype(np.float64) * Q[i[sel]]).sum(1) + 0.25 + bu[u[sel]] + bi[i[sel]]
+    assert_close(a[sel], want, what="sampled logits")

@@ -1,0 +1,817 @@
+// api.hip - the C-ABI of include/tfrecomm.h over the kernels in svd_kernels.hip.
+// Host-side orchestration of one minibatch (svd_train_val.py:66-72):
+//   K1 forward+loss+g  ->  key sorts (user ids, item ids)  ->  item-side segmented reduce
+//   -> user-side segmented reduce (+ fused lazy Adam / SGD)  ->  item apply  ->  finalize
+// or, in TF1 Adam mode, both reduces to scratch followed by the dense sweeps.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <new>
+#include <vector>
+#include "tfrecomm.h"
+#include "svd_kernels.h"
+
+using namespace tfr;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? TFR_ERR_NOMEM : TFR_ERR_HIP, "%s: %s",   \
+                        #expr, hipGetErrorString(e_));                                       \
+    } while (0)
+
+struct ProfEvent { hipEvent_t a, b; int kid; };
+
+struct tfr_model {
+    int64_t U = 0, I = 0;
+    int32_t D = 0, G = 0, VEC = 0;
+    int bits_u = 1, bits_i = 1;
+    tfr_opts o;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // tables: index TFR_MU..TFR_Q; slots m, v
+    float* w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* m[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* v[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t n[5] = {0, 0, 0, 0, 0};
+    uint32_t frozen = 0;
+    int64_t step = 0;
+    float b1p = 0.f, b2p = 0.f;
+    // batch workspace
+    int64_t cap = 0;
+    int32_t *d_u = nullptr, *d_i = nullptr;
+    float *d_r = nullptr, *d_logits = nullptr, *d_g = nullptr;
+    int32_t *iota = nullptr, *ks_u = nullptr, *ps_u = nullptr, *ks_i = nullptr, *ps_i = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    float *gq = nullptr, *gp = nullptr, *gbq = nullptr, *gbp = nullptr;
+    int32_t *map_u = nullptr, *map_i = nullptr;
+    float* partials = nullptr;
+    float* scalars = nullptr;         // {loss, reg, sum_g, -}
+    float* step_out = nullptr;        // per-step {loss, reg, sum_g} ring for multi-step calls
+    int64_t step_out_cap = 0;
+    int32_t* d_err = nullptr;
+    // resident store
+    int32_t *su = nullptr, *si = nullptr;
+    float* sr = nullptr;
+    int64_t N = 0;
+    int64_t* d_ids = nullptr;
+    int64_t n_ids = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEvent> events;
+    double prof_ms[TFR_K_COUNT];
+    int64_t prof_n[TFR_K_COUNT];
+};
+
+// ---------------------------------------------------------------------------------------
+static int bits_for(int64_t rows) {
+    int b = 1;
+    while (((int64_t)1 << b) < rows && b < 31) ++b;
+    return b;
+}
+
+template <typename T>
+static int dmalloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+    return TFR_OK;
+}
+
+static void dfree(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+struct Prof {
+    tfr_model* m;
+    int kid;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(tfr_model* m_, int kid_) : m(m_), kid(kid_) {
+        if (m->prof) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+            (void)hipEventRecord(a, m->stream);
+        }
+    }
+    ~Prof() {
+        if (a && b) {
+            (void)hipEventRecord(b, m->stream);
+            m->events.push_back({a, b, kid});
+        }
+    }
+};
+
+static int drain_profile(tfr_model* m) {
+    if (m->events.empty()) return TFR_OK;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    for (auto& e : m->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            m->prof_ms[e.kid] += ms;
+            m->prof_n[e.kid] += 1;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    m->events.clear();
+    return TFR_OK;
+}
+
+static void free_workspace(tfr_model* m) {
+    dfree(m->d_u); dfree(m->d_i); dfree(m->d_r); dfree(m->d_logits); dfree(m->d_g);
+    dfree(m->iota); dfree(m->ks_u); dfree(m->ps_u); dfree(m->ks_i); dfree(m->ps_i);
+    dfree(m->sort_tmp); dfree(m->gq); dfree(m->gp); dfree(m->gbq); dfree(m->gbp);
+    dfree(m->partials);
+    m->d_u = m->d_i = nullptr; m->d_r = m->d_logits = m->d_g = nullptr;
+    m->iota = m->ks_u = m->ps_u = m->ks_i = m->ps_i = nullptr;
+    m->sort_tmp = nullptr; m->gq = m->gp = m->gbq = m->gbp = nullptr; m->partials = nullptr;
+    m->cap = 0;
+}
+
+static int ensure_capacity(tfr_model* m, int64_t B) {
+    if (B <= m->cap) return TFR_OK;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    free_workspace(m);
+    int64_t cap = 1024;
+    while (cap < B) cap <<= 1;
+    if (cap > (int64_t)1 << 30) return fail(TFR_ERR_ARG, "batch %lld too large", (long long)B);
+    int rc;
+    if ((rc = dmalloc(&m->d_u, cap))) return rc;
+    if ((rc = dmalloc(&m->d_i, cap))) return rc;
+    if ((rc = dmalloc(&m->d_r, cap))) return rc;
+    if ((rc = dmalloc(&m->d_logits, cap))) return rc;
+    if ((rc = dmalloc(&m->d_g, cap))) return rc;
+    if ((rc = dmalloc(&m->iota, cap))) return rc;
+    if ((rc = dmalloc(&m->ks_u, cap))) return rc;
+    if ((rc = dmalloc(&m->ps_u, cap))) return rc;
+    if ((rc = dmalloc(&m->ks_i, cap))) return rc;
+    if ((rc = dmalloc(&m->ps_i, cap))) return rc;
+    size_t tb = sort_temp_bytes(cap, m->bits_u);
+    size_t tb2 = sort_temp_bytes(cap, m->bits_i);
+    if (tb2 > tb) tb = tb2;
+    if (tb == 0) return fail(TFR_ERR_HIP, "radix sort temp-size query failed");
+    tb = 2 * tb + (1 << 20);          // head-room: smaller batches may pick another rocPRIM path
+    m->sort_tmp_bytes = tb;
+    HIPCHK(hipMalloc(&m->sort_tmp, tb));
+    if ((rc = dmalloc(&m->gq, (size_t)cap * m->D))) return rc;
+    if ((rc = dmalloc(&m->gbq, cap))) return rc;
+    if ((rc = dmalloc(&m->gbp, cap))) return rc;
+    if (m->o.optimizer == TFR_OPT_ADAM && m->o.adam_mode == TFR_ADAM_TF1)
+        if ((rc = dmalloc(&m->gp, (size_t)cap * m->D))) return rc;
+    if ((rc = dmalloc(&m->partials, (size_t)2048 * 4))) return rc;
+    launch_iota(m->iota, cap, m->stream);
+    HIPCHK(hipGetLastError());
+    m->cap = cap;
+    return TFR_OK;
+}
+
+static int ensure_step_out(tfr_model* m, int64_t nsteps) {
+    if (nsteps <= m->step_out_cap) return TFR_OK;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    dfree(m->step_out);
+    m->step_out = nullptr;
+    m->step_out_cap = 0;
+    int rc;
+    if ((rc = dmalloc(&m->step_out, (size_t)nsteps * 4))) return rc;
+    m->step_out_cap = nsteps;
+    return TFR_OK;
+}
+
+// read + clear the device error flag (stream must be idle or this call synchronises)
+static int check_device_error(tfr_model* m) {
+    int32_t e = 0;
+    HIPCHK(hipMemcpyAsync(&e, m->d_err, sizeof(e), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (e) {
+        HIPCHK(hipMemsetAsync(m->d_err, 0, sizeof(int32_t), m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (e & 1) return fail(TFR_ERR_OOB, "user/item id out of range [0,%lld) / [0,%lld)",
+                               (long long)m->U, (long long)m->I);
+        return fail(TFR_ERR_OOB, "store index out of range [0,%lld)", (long long)m->N);
+    }
+    return TFR_OK;
+}
+
+#define MODEL_ENTER(m)                                                \
+    if (!(m)) return fail(TFR_ERR_ARG, "null model");                 \
+    HIPCHK(hipSetDevice((m)->device));
+
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+void tfr_default_opts(tfr_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->loss = TFR_LOSS_MSE;
+    o->optimizer = TFR_OPT_ADAM;
+    o->adam_mode = TFR_ADAM_TF1;
+    o->lr = 1e-3f;
+    o->reg = 0.05f;
+    o->beta1 = 0.9f;
+    o->beta2 = 0.999f;
+    o->eps = 1e-8f;
+}
+
+int tfr_version(void) { return TFR_ABI_VERSION; }
+
+const char* tfr_last_error(void) { return g_err; }
+
+int tfr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tfr_destroy(tfr_model* m) {
+    if (!m) return TFR_OK;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (auto& e : m->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    free_workspace(m);
+    for (int t = 0; t < 5; ++t) { dfree(m->w[t]); dfree(m->m[t]); dfree(m->v[t]); }
+    dfree(m->map_u); dfree(m->map_i); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
+    dfree(m->su); dfree(m->si); dfree(m->sr); dfree(m->d_ids);
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    delete m;
+    return TFR_OK;
+}
+
+int tfr_create(tfr_model** out, int64_t U, int64_t I, int32_t D, const tfr_opts* opts) {
+    if (!out) return fail(TFR_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!opts) return fail(TFR_ERR_ARG, "opts is null");
+    if (U < 1 || I < 1 || U > 0x7fffffffLL || I > 0x7fffffffLL)
+        return fail(TFR_ERR_ARG, "user_num/item_num must be in [1, 2^31)");
+    int G, VEC;
+    if (!geometry(D, &G, &VEC))
+        return fail(TFR_ERR_ARG, "unsupported dim %d (need dim %% 4 == 0 and dim <= 256, or dim <= 64)", D);
+    if (opts->loss != TFR_LOSS_MSE && opts->loss != TFR_LOSS_NLL) return fail(TFR_ERR_ARG, "bad loss");
+    if (opts->optimizer != TFR_OPT_ADAM && opts->optimizer != TFR_OPT_SGD) return fail(TFR_ERR_ARG, "bad optimizer");
+    if (opts->adam_mode != TFR_ADAM_TF1 && opts->adam_mode != TFR_ADAM_LAZY) return fail(TFR_ERR_ARG, "bad adam_mode");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(TFR_ERR_HIP, "no HIP device available (%s) - this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (opts->device < 0 || opts->device >= ndev) return fail(TFR_ERR_ARG, "device %d not in [0,%d)", opts->device, ndev);
+    HIPCHK(hipSetDevice(opts->device));
+    tfr_model* m = new (std::nothrow) tfr_model();
+    if (!m) return fail(TFR_ERR_NOMEM, "host allocation failed");
+    m->U = U; m->I = I; m->D = D; m->G = G; m->VEC = VEC;
+    m->o = *opts;
+    m->device = opts->device;
+    m->bits_u = bits_for(U);
+    m->bits_i = bits_for(I);
+    m->n[TFR_MU] = 1; m->n[TFR_BU] = U; m->n[TFR_BI] = I; m->n[TFR_P] = U * D; m->n[TFR_Q] = I * D;
+    m->b1p = opts->beta1;
+    m->b2p = opts->beta2;
+    memset(m->prof_ms, 0, sizeof(m->prof_ms));
+    memset(m->prof_n, 0, sizeof(m->prof_n));
+    int rc = TFR_OK;
+    do {
+        if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(TFR_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        m->stream = m->own_stream;
+        const bool adam = opts->optimizer == TFR_OPT_ADAM;
+        for (int t = 0; t < 5 && rc == TFR_OK; ++t) {
+            rc = dmalloc(&m->w[t], (size_t)m->n[t]);
+            if (rc == TFR_OK && hipMemsetAsync(m->w[t], 0, (size_t)m->n[t] * 4, m->stream) != hipSuccess)
+                rc = fail(TFR_ERR_HIP, "memset failed");
+            if (rc == TFR_OK && adam) {
+                rc = dmalloc(&m->m[t], (size_t)m->n[t]);
+                if (rc == TFR_OK) rc = dmalloc(&m->v[t], (size_t)m->n[t]);
+                if (rc == TFR_OK && (hipMemsetAsync(m->m[t], 0, (size_t)m->n[t] * 4, m->stream) != hipSuccess ||
+                                     hipMemsetAsync(m->v[t], 0, (size_t)m->n[t] * 4, m->stream) != hipSuccess))
+                    rc = fail(TFR_ERR_HIP, "memset failed");
+            }
+        }
+        if (rc) break;
+        if (adam && opts->adam_mode == TFR_ADAM_TF1) {
+            if ((rc = dmalloc(&m->map_u, (size_t)U))) break;
+            if ((rc = dmalloc(&m->map_i, (size_t)I))) break;
+            if (hipMemsetAsync(m->map_u, 0, (size_t)U * 4, m->stream) != hipSuccess ||
+                hipMemsetAsync(m->map_i, 0, (size_t)I * 4, m->stream) != hipSuccess) {
+                rc = fail(TFR_ERR_HIP, "memset failed");
+                break;
+            }
+        }
+        if ((rc = dmalloc(&m->scalars, 4))) break;
+        if ((rc = dmalloc(&m->d_err, 1))) break;
+        if (hipMemsetAsync(m->scalars, 0, 16, m->stream) != hipSuccess ||
+            hipMemsetAsync(m->d_err, 0, 4, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess) {
+            rc = fail(TFR_ERR_HIP, "init failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    if (rc) {
+        char keep[512];
+        strncpy(keep, g_err, sizeof(keep));
+        tfr_destroy(m);
+        strncpy(g_err, keep, sizeof(g_err));
+        return rc;
+    }
+    *out = m;
+    return TFR_OK;
+}
+
+// ---- variables -------------------------------------------------------------------------
+static int table_ptr(tfr_model* m, int32_t which, float** p, int64_t* n) {
+    const int t = which & 7;
+    if (t > TFR_Q || (which & ~(7 | TFR_SLOT_M | TFR_SLOT_V)) || ((which & TFR_SLOT_M) && (which & TFR_SLOT_V)))
+        return fail(TFR_ERR_ARG, "bad table id %d", which);
+    float* q = (which & TFR_SLOT_M) ? m->m[t] : (which & TFR_SLOT_V) ? m->v[t] : m->w[t];
+    if (!q) return fail(TFR_ERR_STATE, "table %d has no such slot (optimizer is not Adam)", which);
+    *p = q;
+    *n = m->n[t];
+    return TFR_OK;
+}
+
+int tfr_set_table(tfr_model* m, int32_t which, const float* host, int64_t n) {
+    MODEL_ENTER(m);
+    float* p; int64_t cnt;
+    int rc = table_ptr(m, which, &p, &cnt);
+    if (rc) return rc;
+    if (!host || n != cnt) return fail(TFR_ERR_ARG, "table %d expects %lld floats, got %lld", which, (long long)cnt, (long long)n);
+    HIPCHK(hipMemcpyAsync(p, host, (size_t)n * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return TFR_OK;
+}
+
+int tfr_get_table(tfr_model* m, int32_t which, float* host, int64_t n) {
+    MODEL_ENTER(m);
+    float* p; int64_t cnt;
+    int rc = table_ptr(m, which, &p, &cnt);
+    if (rc) return rc;
+    if (!host || n != cnt) return fail(TFR_ERR_ARG, "table %d holds %lld floats, asked %lld", which, (long long)cnt, (long long)n);
+    HIPCHK(hipMemcpyAsync(host, p, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return TFR_OK;
+}
+
+int tfr_table_devptr(tfr_model* m, int32_t which, void** ptr, int64_t* n) {
+    MODEL_ENTER(m);
+    float* p; int64_t cnt;
+    int rc = table_ptr(m, which, &p, &cnt);
+    if (rc) return rc;
+    if (ptr) *ptr = p;
+    if (n) *n = cnt;
+    return TFR_OK;
+}
+
+int tfr_scalars_devptr(tfr_model* m, void** ptr) {
+    MODEL_ENTER(m);
+    if (ptr) *ptr = m->scalars;
+    return TFR_OK;
+}
+
+int tfr_set_frozen(tfr_model* m, uint32_t mask) {
+    MODEL_ENTER(m);
+    if (mask >> 5) return fail(TFR_ERR_ARG, "frozen mask has bits beyond the 5 tables");
+    m->frozen = mask;
+    return TFR_OK;
+}
+
+int tfr_get_step(tfr_model* m, int64_t* step, float* b1p, float* b2p) {
+    MODEL_ENTER(m);
+    if (step) *step = m->step;
+    if (b1p) *b1p = m->b1p;
+    if (b2p) *b2p = m->b2p;
+    return TFR_OK;
+}
+
+int tfr_set_step(tfr_model* m, int64_t step, float b1p, float b2p) {
+    MODEL_ENTER(m);
+    if (step < 0) return fail(TFR_ERR_ARG, "negative step");
+    m->step = step;
+    m->b1p = b1p;
+    m->b2p = b2p;
+    return TFR_OK;
+}
+
+int tfr_set_hyper(tfr_model* m, float lr, float reg) {
+    MODEL_ENTER(m);
+    m->o.lr = lr;
+    m->o.reg = reg;
+    return TFR_OK;
+}
+
+int tfr_set_stream(tfr_model* m, void* s) {
+    MODEL_ENTER(m);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->stream = s ? (hipStream_t)s : m->own_stream;
+    return TFR_OK;
+}
+
+int tfr_get_stream(tfr_model* m, void** s) {
+    MODEL_ENTER(m);
+    if (s) *s = (void*)m->stream;
+    return TFR_OK;
+}
+
+int tfr_sync(tfr_model* m) {
+    MODEL_ENTER(m);
+    return check_device_error(m);
+}
+
+int tfr_profile(tfr_model* m, int32_t enable) {
+    MODEL_ENTER(m);
+    int rc = drain_profile(m);
+    if (rc) return rc;
+    if (enable) {
+        memset(m->prof_ms, 0, sizeof(m->prof_ms));
+        memset(m->prof_n, 0, sizeof(m->prof_n));
+    }
+    m->prof = enable != 0;
+    return TFR_OK;
+}
+
+int tfr_profile_read(tfr_model* m, int32_t kernel, double* total_ms, int64_t* launches) {
+    MODEL_ENTER(m);
+    if (kernel < 0 || kernel >= TFR_K_COUNT) return fail(TFR_ERR_ARG, "bad kernel id");
+    int rc = drain_profile(m);
+    if (rc) return rc;
+    if (total_ms) *total_ms = m->prof_ms[kernel];
+    if (launches) *launches = m->prof_n[kernel];
+    return TFR_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// forward on device-resident ids
+static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t* di, const float* dr,
+                       int64_t B, float* d_logits, float* d_g, int* nblk_out) {
+    FwdArgs a;
+    a.P = m->w[TFR_P]; a.Q = m->w[TFR_Q]; a.bu = m->w[TFR_BU]; a.bi = m->w[TFR_BI]; a.mu = m->w[TFR_MU];
+    a.u = du; a.it = di; a.r = dr;
+    a.logits = d_logits; a.g = d_g; a.partials = m->partials; a.err = m->d_err;
+    a.B = B; a.U = m->U; a.I = m->I;
+    a.D = m->D; a.loss = m->o.loss; a.item_abs = m->o.item_abs; a.reg_bias = m->o.reg_bias;
+    const int grid = forward_grid(B, m->G);
+    if (nblk_out) *nblk_out = grid;
+    {
+        Prof p(m, TFR_K_FORWARD);
+        launch_forward(a, mode, m->G, m->VEC, grid, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
+// one minibatch on device-resident (u, i, r); out3 = optional device {loss, reg, sum_g} slot
+static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
+                          float* d_logits, float* out3) {
+    const tfr_opts& o = m->o;
+    const bool adam = o.optimizer == TFR_OPT_ADAM;
+    const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
+    // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like the TF graph [TF1-lib]
+    const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
+    int nblk = 0;
+    hipStream_t s = m->stream;
+    if (B > 0) {
+        int rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk);
+        if (rc) return rc;
+        {
+            Prof p(m, TFR_K_SORT);
+            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, di, m->ks_i, m->iota, m->ps_i, B, m->bits_i, s));
+            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, du, m->ks_u, m->iota, m->ps_u, B, m->bits_u, s));
+        }
+        RedArgs r;
+        memset(&r, 0, sizeof(r));
+        r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
+        r.chunk = 4;
+        r.item_abs = o.item_abs; r.reg_bias = o.reg_bias;
+        r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
+        // item side -> scratch (reads the pre-update user rows)
+        RedArgs ri = r;
+        ri.side = 1;
+        ri.ks = m->ks_i; ri.ps = m->ps_i; ri.other = du;
+        ri.own = m->w[TFR_Q]; ri.partner = m->w[TFR_P]; ri.own_bias = m->w[TFR_BI];
+        ri.grad_rows = m->gq; ri.grad_bias = m->gbq; ri.map = tf1 ? m->map_i : nullptr;
+        {
+            Prof p(m, TFR_K_REDUCE_ITEM);
+            launch_seg_reduce(ri, RMODE_SCRATCH, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        // user side: fused update (lazy Adam / SGD) or scratch (TF1 Adam)
+        RedArgs ru = r;
+        ru.side = 0;
+        ru.ks = m->ks_u; ru.ps = m->ps_u; ru.other = di;
+        ru.own = m->w[TFR_P]; ru.partner = m->w[TFR_Q]; ru.own_bias = m->w[TFR_BU];
+        ru.own_w = m->w[TFR_P]; ru.m = m->m[TFR_P]; ru.v = m->v[TFR_P];
+        ru.bias_w = m->w[TFR_BU]; ru.bias_m = m->m[TFR_BU]; ru.bias_v = m->v[TFR_BU];
+        ru.grad_rows = m->gp; ru.grad_bias = m->gbp; ru.map = tf1 ? m->map_u : nullptr;
+        ru.frozen_rows = (m->frozen >> TFR_P) & 1; ru.frozen_bias = (m->frozen >> TFR_BU) & 1;
+        {
+            Prof p(m, TFR_K_REDUCE_USER);
+            launch_seg_reduce(ru, tf1 ? RMODE_SCRATCH : (adam ? RMODE_ADAM : RMODE_SGD), m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        if (!tf1) {
+            ApplyArgs ap;
+            memset(&ap, 0, sizeof(ap));
+            ap.ks = m->ks_i; ap.grad_rows = m->gq; ap.grad_bias = m->gbq;
+            ap.w = m->w[TFR_Q]; ap.m = m->m[TFR_Q]; ap.v = m->v[TFR_Q];
+            ap.bias_w = m->w[TFR_BI]; ap.bias_m = m->m[TFR_BI]; ap.bias_v = m->v[TFR_BI];
+            ap.err = m->d_err; ap.B = B; ap.D = m->D; ap.chunk = 4;
+            ap.frozen_rows = (m->frozen >> TFR_Q) & 1; ap.frozen_bias = (m->frozen >> TFR_BI) & 1;
+            ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
+            {
+                Prof p(m, TFR_K_APPLY);
+                launch_apply_rows(ap, adam ? 0 : 1, m->G, m->VEC, s);
+            }
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (tf1) {
+        // dense sweeps: every row of every unfrozen table moves
+        Prof p(m, TFR_K_APPLY);
+        DenseArgs d;
+        memset(&d, 0, sizeof(d));
+        d.err = m->d_err; d.D = m->D;
+        d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps;
+        DenseArgs dp = d;
+        dp.map = m->map_u; dp.grad_rows = m->gp; dp.grad_bias = m->gbp; dp.rows = m->U;
+        dp.w = m->w[TFR_P]; dp.m = m->m[TFR_P]; dp.v = m->v[TFR_P];
+        dp.bias_w = m->w[TFR_BU]; dp.bias_m = m->m[TFR_BU]; dp.bias_v = m->v[TFR_BU];
+        dp.frozen_rows = (m->frozen >> TFR_P) & 1; dp.frozen_bias = (m->frozen >> TFR_BU) & 1;
+        if (!(dp.frozen_rows && dp.frozen_bias)) launch_adam_dense(dp, m->G, m->VEC, s);
+        DenseArgs dq = d;
+        dq.map = m->map_i; dq.grad_rows = m->gq; dq.grad_bias = m->gbq; dq.rows = m->I;
+        dq.w = m->w[TFR_Q]; dq.m = m->m[TFR_Q]; dq.v = m->v[TFR_Q];
+        dq.bias_w = m->w[TFR_BI]; dq.bias_m = m->m[TFR_BI]; dq.bias_v = m->v[TFR_BI];
+        dq.frozen_rows = (m->frozen >> TFR_Q) & 1; dq.frozen_bias = (m->frozen >> TFR_BI) & 1;
+        if (!(dq.frozen_rows && dq.frozen_bias)) launch_adam_dense(dq, m->G, m->VEC, s);
+        if (B > 0) {
+            launch_clear_map(m->ks_u, B, m->map_u, m->d_err, s);
+            launch_clear_map(m->ks_i, B, m->map_i, m->d_err, s);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.partials = m->partials; f.nblk = nblk; f.scalars = m->scalars; f.out = out3;
+    f.mu = m->w[TFR_MU]; f.mu_m = m->m[TFR_MU]; f.mu_v = m->v[TFR_MU]; f.err = m->d_err;
+    f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
+    f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
+    {
+        Prof p(m, TFR_K_FINALIZE);
+        launch_finalize(f, s);
+    }
+    HIPCHK(hipGetLastError());
+    if (adam) {                       // beta-power accumulators advance after the applies [TF1-lib]
+        m->b1p *= o.beta1;
+        m->b2p *= o.beta2;
+    }
+    m->step += 1;
+    return TFR_OK;
+}
+
+static void rollback_step(tfr_model* m, int64_t step0, float b1p0, float b2p0) {
+    m->step = step0;
+    m->b1p = b1p0;
+    m->b2p = b2p0;
+}
+
+static int check_batch(const void* u, const void* i, int64_t B) {
+    if (B < 0) return fail(TFR_ERR_ARG, "negative batch");
+    if (B > 0 && (!u || !i)) return fail(TFR_ERR_ARG, "null id pointer");
+    return TFR_OK;
+}
+
+extern "C" {
+
+// ---- forward ---------------------------------------------------------------------------
+int tfr_forward_dev(tfr_model* m, const int32_t* du, const int32_t* di, int64_t B, float* d_logits) {
+    MODEL_ENTER(m);
+    int rc = check_batch(du, di, B);
+    if (rc) return rc;
+    if (B == 0) return TFR_OK;
+    if (!d_logits) return fail(TFR_ERR_ARG, "null logits pointer");
+    if ((rc = ensure_capacity(m, 1))) return rc;
+    return run_forward(m, MODE_INFER, du, di, nullptr, B, d_logits, nullptr, nullptr);
+}
+
+int tfr_forward(tfr_model* m, const int32_t* u, const int32_t* i, int64_t B, float* logits_out) {
+    MODEL_ENTER(m);
+    int rc = check_batch(u, i, B);
+    if (rc) return rc;
+    if (B == 0) return TFR_OK;
+    if (!logits_out) return fail(TFR_ERR_ARG, "null logits pointer");
+    if ((rc = ensure_capacity(m, B))) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    if ((rc = run_forward(m, MODE_INFER, m->d_u, m->d_i, nullptr, B, m->d_logits, nullptr, nullptr))) return rc;
+    HIPCHK(hipMemcpyAsync(logits_out, m->d_logits, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    return check_device_error(m);
+}
+
+int tfr_eval(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t B,
+             double* sse_out, int64_t* neq_out) {
+    MODEL_ENTER(m);
+    int rc = check_batch(u, i, B);
+    if (rc) return rc;
+    if (sse_out) *sse_out = 0.0;
+    if (neq_out) *neq_out = 0;
+    if (B == 0) return TFR_OK;
+    if (!r) return fail(TFR_ERR_ARG, "null rate pointer");
+    if ((rc = ensure_capacity(m, B))) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_r, r, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    int nblk = 0;
+    if ((rc = run_forward(m, MODE_EVAL, m->d_u, m->d_i, m->d_r, B, nullptr, nullptr, &nblk))) return rc;
+    std::vector<float> part((size_t)nblk * 4);
+    HIPCHK(hipMemcpyAsync(part.data(), m->partials, part.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    if ((rc = check_device_error(m))) return rc;
+    double sse = 0.0;
+    int64_t neq = 0;
+    for (int b = 0; b < nblk; ++b) {
+        sse += (double)part[(size_t)b * 4 + 0];
+        neq += (int64_t)llround((double)part[(size_t)b * 4 + 1]);
+    }
+    if (sse_out) *sse_out = sse;
+    if (neq_out) *neq_out = neq;
+    return TFR_OK;
+}
+
+// ---- one minibatch ---------------------------------------------------------------------
+int tfr_train_step_dev(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
+                       float* d_logits) {
+    MODEL_ENTER(m);
+    int rc = check_batch(du, di, B);
+    if (rc) return rc;
+    if (B > 0 && !dr) return fail(TFR_ERR_ARG, "null rate pointer");
+    if ((rc = ensure_capacity(m, B > 0 ? B : 1))) return rc;
+    return run_train_step(m, du, di, dr, B, d_logits, nullptr);
+}
+
+int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t B,
+                   float* logits_out, float* loss_out, float* reg_out) {
+    MODEL_ENTER(m);
+    int rc = check_batch(u, i, B);
+    if (rc) return rc;
+    if (B > 0 && !r) return fail(TFR_ERR_ARG, "null rate pointer");
+    if ((rc = ensure_capacity(m, B > 0 ? B : 1))) return rc;
+    if (B > 0) {
+        HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(m->d_r, r, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    }
+    const int64_t step0 = m->step;
+    const float b1p0 = m->b1p, b2p0 = m->b2p;
+    if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, logits_out ? m->d_logits : nullptr, nullptr))) return rc;
+    float sc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (logits_out && B > 0)
+        HIPCHK(hipMemcpyAsync(logits_out, m->d_logits, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(sc, m->scalars, 16, hipMemcpyDeviceToHost, m->stream));
+    // synchronous entry point: always validate so a bad batch never advances the step
+    if ((rc = check_device_error(m))) {
+        rollback_step(m, step0, b1p0, b2p0);
+        return rc;
+    }
+    if (loss_out) *loss_out = sc[0];
+    if (reg_out) *reg_out = sc[1];
+    return TFR_OK;
+}
+
+// ---- resident store --------------------------------------------------------------------
+int tfr_upload_triples(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t N) {
+    MODEL_ENTER(m);
+    if (N < 1 || !u || !i || !r) return fail(TFR_ERR_ARG, "upload_triples: need n >= 1 and non-null columns");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    dfree(m->su); dfree(m->si); dfree(m->sr);
+    m->su = m->si = nullptr; m->sr = nullptr; m->N = 0;
+    int rc;
+    if ((rc = dmalloc(&m->su, (size_t)N))) return rc;
+    if ((rc = dmalloc(&m->si, (size_t)N))) return rc;
+    if ((rc = dmalloc(&m->sr, (size_t)N))) return rc;
+    HIPCHK(hipMemcpyAsync(m->su, u, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->si, i, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->sr, r, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->N = N;
+    return TFR_OK;
+}
+
+int tfr_stage_ids(tfr_model* m, const int64_t* ids, int64_t n) {
+    MODEL_ENTER(m);
+    if (n < 1 || !ids) return fail(TFR_ERR_ARG, "stage_ids: need n >= 1 and non-null ids");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    dfree(m->d_ids);
+    m->d_ids = nullptr; m->n_ids = 0;
+    int rc;
+    if ((rc = dmalloc(&m->d_ids, (size_t)n))) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_ids, ids, (size_t)n * 8, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->n_ids = n;
+    return TFR_OK;
+}
+
+static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t B) {
+    GatherArgs g;
+    g.ids = d_ids; g.lo = lo; g.B = B; g.N = m->N;
+    g.su = m->su; g.si = m->si; g.sr = m->sr;
+    g.u = m->d_u; g.it = m->d_i; g.r = m->d_r; g.err = m->d_err;
+    {
+        Prof p(m, TFR_K_GATHER);
+        launch_gather(g, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
+static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nsteps, float* loss_out) {
+    int rc;
+    if ((rc = ensure_capacity(m, B))) return rc;
+    if (loss_out && (rc = ensure_step_out(m, nsteps))) return rc;
+    const int64_t step0 = m->step;
+    const float b1p0 = m->b1p, b2p0 = m->b2p;
+    for (int32_t s = 0; s < nsteps; ++s) {
+        if ((rc = gather_batch(m, m->d_ids + (first_step + s) * B, 0, B))) return rc;
+        if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr,
+                                 loss_out ? m->step_out + (size_t)s * 4 : nullptr)))
+            return rc;
+    }
+    if (loss_out) {
+        std::vector<float> tmp((size_t)nsteps * 4);
+        HIPCHK(hipMemcpyAsync(tmp.data(), m->step_out, tmp.size() * 4, hipMemcpyDeviceToHost, m->stream));
+        if ((rc = check_device_error(m))) {
+            rollback_step(m, step0, b1p0, b2p0);
+            return rc;
+        }
+        for (int32_t s = 0; s < nsteps; ++s) loss_out[s] = tmp[(size_t)s * 4];
+    }
+    return TFR_OK;
+}
+
+int tfr_train_steps_staged(tfr_model* m, int64_t first_step, int64_t B, int32_t nsteps, float* loss_out) {
+    MODEL_ENTER(m);
+    if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples first");
+    if (!m->d_ids) return fail(TFR_ERR_STATE, "no staged ids: call tfr_stage_ids first");
+    if (B < 1 || nsteps < 0 || first_step < 0) return fail(TFR_ERR_ARG, "bad batch/nsteps/first_step");
+    if ((first_step + nsteps) * B > m->n_ids)
+        return fail(TFR_ERR_ARG, "steps [%lld,%lld) x batch %lld exceed the %lld staged ids", (long long)first_step,
+                    (long long)(first_step + nsteps), (long long)B, (long long)m->n_ids);
+    return staged_steps(m, first_step, B, nsteps, loss_out);
+}
+
+int tfr_train_steps_resident(tfr_model* m, const int64_t* ids, int64_t B, int32_t nsteps, float* loss_out) {
+    MODEL_ENTER(m);
+    if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples first");
+    if (B < 1 || nsteps < 0 || !ids) return fail(TFR_ERR_ARG, "bad batch/nsteps/ids");
+    if (nsteps == 0) return TFR_OK;
+    int rc = tfr_stage_ids(m, ids, B * nsteps);
+    if (rc) return rc;
+    return staged_steps(m, 0, B, nsteps, loss_out);
+}
+
+int tfr_forward_resident(tfr_model* m, int64_t lo, int64_t hi, float* logits_out) {
+    MODEL_ENTER(m);
+    if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples first");
+    if (lo < 0 || hi < lo || hi > m->N) return fail(TFR_ERR_ARG, "bad store range [%lld,%lld)", (long long)lo, (long long)hi);
+    const int64_t B = hi - lo;
+    if (B == 0) return TFR_OK;
+    int rc;
+    if ((rc = ensure_capacity(m, B))) return rc;
+    if ((rc = gather_batch(m, nullptr, lo, B))) return rc;
+    if ((rc = run_forward(m, MODE_INFER, m->d_u, m->d_i, nullptr, B, m->d_logits, nullptr, nullptr))) return rc;
+    if (logits_out) {
+        HIPCHK(hipMemcpyAsync(logits_out, m->d_logits, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+        return check_device_error(m);
+    }
+    return TFR_OK;
+}
+
+int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t B, int32_t* ks_out, int32_t* ps_out) {
+    MODEL_ENTER(m);
+    if (side != 0 && side != 1) return fail(TFR_ERR_ARG, "side must be 0 (user) or 1 (item)");
+    if (B < 0 || (B > 0 && (!ids || !ks_out || !ps_out))) return fail(TFR_ERR_ARG, "bad batch / null pointer");
+    if (B == 0) return TFR_OK;
+    int rc;
+    if ((rc = ensure_capacity(m, B))) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_u, ids, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, m->d_u, m->ks_u, m->iota, m->ps_u, B,
+                      side == 0 ? m->bits_u : m->bits_i, m->stream));
+    HIPCHK(hipMemcpyAsync(ks_out, m->ks_u, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(ps_out, m->ps_u, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return TFR_OK;
+}
+
+}  // extern "C"

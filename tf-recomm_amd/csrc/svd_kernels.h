@@ -1,0 +1,91 @@
+// svd_kernels.h - argument blocks and launchers shared by svd_kernels.hip and api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfr {
+
+enum { MODE_INFER = 0, MODE_TRAIN = 1, MODE_EVAL = 2 };
+enum { RMODE_SCRATCH = 0, RMODE_ADAM = 1, RMODE_SGD = 2 };
+
+struct FwdArgs {
+    const float* P; const float* Q; const float* bu; const float* bi; const float* mu;
+    const int32_t* u; const int32_t* it; const float* r;
+    float* logits; float* g; float* partials; int32_t* err;
+    int64_t B, U, I;
+    int32_t D, loss, item_abs, reg_bias;
+};
+
+struct GatherArgs {
+    const int64_t* ids;          // NULL -> contiguous range starting at lo
+    int64_t lo, B, N;
+    const int32_t* su; const int32_t* si; const float* sr;
+    int32_t* u; int32_t* it; float* r; int32_t* err;
+};
+
+struct RedArgs {
+    const int32_t* ks; const int32_t* ps; const int32_t* other; const float* g;
+    const float* own; const float* partner; const float* own_bias;
+    float* own_w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
+    float* grad_rows; float* grad_bias; int32_t* map;
+    const int32_t* err;
+    int64_t B;
+    int32_t D, chunk, side, item_abs, reg_bias, frozen_rows, frozen_bias;
+    float lam, alpha, b1, b2, eps, lr;
+};
+
+struct ApplyArgs {
+    const int32_t* ks; const float* grad_rows; const float* grad_bias;
+    float* w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
+    const int32_t* err;
+    int64_t B;
+    int32_t D, chunk, frozen_rows, frozen_bias;
+    float alpha, b1, b2, eps, lr;
+};
+
+struct DenseArgs {
+    const int32_t* map; const float* grad_rows; const float* grad_bias;
+    float* w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
+    const int32_t* err;
+    int64_t rows;
+    int32_t D, frozen_rows, frozen_bias;
+    float alpha, b1, b2, eps;
+};
+
+struct FinArgs {
+    const float* partials; int32_t nblk;
+    float* scalars; float* out;
+    float* mu; float* mu_m; float* mu_v; const int32_t* err;
+    int32_t update_mu, opt;
+    float alpha, b1, b2, eps, lr;
+};
+
+// row geometry for a dim: returns false if unsupported
+inline bool geometry(int D, int* G, int* VEC) {
+    if (D < 1) return false;
+    int vec = (D % 4 == 0) ? 4 : 1;
+    int lanes = (D + vec - 1) / vec;
+    int g = 4;
+    while (g < lanes) g <<= 1;
+    if (g > 64) return false;
+    *G = g; *VEC = vec;
+    return true;
+}
+
+int forward_grid(int64_t B, int G);
+void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s);
+void launch_seg_reduce(const RedArgs& a, int rmode, int G, int VEC, hipStream_t s);
+void launch_apply_rows(const ApplyArgs& a, int opt, int G, int VEC, hipStream_t s);
+void launch_adam_dense(const DenseArgs& a, int G, int VEC, hipStream_t s);
+void launch_clear_map(const int32_t* ks, int64_t B, int32_t* map, const int32_t* err, hipStream_t s);
+void launch_gather(const GatherArgs& a, hipStream_t s);
+void launch_iota(int32_t* p, int64_t n, hipStream_t s);
+void launch_finalize(const FinArgs& a, hipStream_t s);
+
+// sort.hip (rocPRIM radix sort; integer work, stable)
+size_t sort_temp_bytes(int64_t n, int end_bit);
+hipError_t sort_pairs(void* temp, size_t temp_bytes, const int32_t* keys_in, int32_t* keys_out,
+                      const int32_t* vals_in, int32_t* vals_out, int64_t n, int end_bit,
+                      hipStream_t s);
+
+}  // namespace tfr

@@ -1,0 +1,549 @@
+// svd_kernels.hip - gfx950 kernels of the SVD minibatch step (wave64, no MFMA: this is a
+// batched gather-dot and a segmented scatter, HBM-bound).
+//
+// Row geometry: one table row of D floats is spread over a lane group of G lanes, VEC
+// floats per lane (G*VEC >= D), so a wave64 holds 64/G rows at once and a full group
+// reads its row as one contiguous, 16-byte-per-lane burst (D=128: 32 lanes x float4 =
+// 512 B).  D % 4 == 0 -> VEC=4 (global_load_dwordx4); otherwise VEC=1 (rows are then not
+// 16-byte aligned; correctness path for the reference's dim=5/15).
+//
+// Reference semantics restated per kernel; file:line into the reference tree.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "svd_kernels.h"
+
+namespace tfr {
+
+// ------------------------------------------------------------------------------------
+template <int VEC> struct Frag { float v[VEC]; };
+
+template <int VEC>
+__device__ __forceinline__ Frag<VEC> load_frag(const float* __restrict__ row, int d0, int D) {
+    Frag<VEC> f;
+    if constexpr (VEC == 4) {
+        if (d0 < D) {
+            const float4 t = *reinterpret_cast<const float4*>(row + d0);
+            f.v[0] = t.x; f.v[1] = t.y; f.v[2] = t.z; f.v[3] = t.w;
+        } else {
+            f.v[0] = f.v[1] = f.v[2] = f.v[3] = 0.f;
+        }
+    } else {
+        f.v[0] = (d0 < D) ? row[d0] : 0.f;
+    }
+    return f;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_frag(float* __restrict__ row, int d0, int D, const Frag<VEC>& f) {
+    if (d0 < D) {
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(row + d0) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+        } else {
+            row[d0] = f.v[0];
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float x) {
+    // butterfly over the G lanes of a group (G is a power of two <= 64); every lane of the
+    // group ends with the same sum, in a fixed order -> deterministic.
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;   // valid in lane 0
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// block-level sum of NV values per thread -> out[NV] written by thread 0.  256 threads.
+template <int NV>
+__device__ __forceinline__ void block_sum_store(float (&val)[NV], float* out) {
+    __shared__ float red[4][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const float s = wave_sum(val[c]);
+        if (lane == 0) red[wave][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) out[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1  gather-dot forward (ops.py:13-14,37-38 embedding_lookup x4; ops.py:44-47 dot + biases)
+//     MODE_INFER: logits only                          (svd_train_val.py:120-122)
+//     MODE_TRAIN: + g = dcost/dlogit, per-block partial {data loss, regulariser, sum g}
+//                 (ops.py:81-89 regulariser over gathered rows; ops.py:124 / 125-126 loss)
+//     MODE_EVAL : per-block partial {sum (infer-rate)^2, count infer==rate}
+//                 (svd_train_val.py:144-149)
+// A lane group owns one rating at a time; UNR ratings are in flight per group so each
+// lane has 2*UNR independent 16-byte loads outstanding.
+template <int G, int VEC, int MODE>
+__global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
+    constexpr int SPW = 64 / G;        // ratings per wave per pass
+    constexpr int UNR = 4;             // passes in flight
+    constexpr int SPI = SPW * UNR;     // ratings per wave-iteration
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / G;
+    const int gl = lane % G;
+    const int d0 = gl * VEC;
+    const int D = a.D;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float mu = *a.mu;
+
+    float acc[3] = {0.f, 0.f, 0.f};    // TRAIN: loss, reg, sum g | EVAL: sse, n_equal, -
+    bool oob = false;
+
+    for (int64_t base = wave_id * SPI; base < a.B; base += nwaves * SPI) {
+        int64_t k[UNR];
+        int32_t u[UNR], it[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            k[j] = base + j * SPW + sub;
+            ok[j] = k[j] < a.B;
+            u[j] = ok[j] ? a.u[k[j]] : 0;
+            it[j] = ok[j] ? a.it[k[j]] : 0;
+            if ((uint64_t)(int64_t)u[j] >= (uint64_t)a.U) { oob = true; u[j] = 0; }
+            if ((uint64_t)(int64_t)it[j] >= (uint64_t)a.I) { oob = true; it[j] = 0; }
+        }
+        Frag<VEC> p[UNR], q[UNR];
+        float bsum[UNR], bu_[UNR], bi_[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            p[j] = load_frag<VEC>(a.P + (size_t)u[j] * D, d0, D);
+            q[j] = load_frag<VEC>(a.Q + (size_t)it[j] * D, d0, D);
+            bu_[j] = a.bu[u[j]];
+            bi_[j] = a.bi[it[j]];
+            bsum[j] = bu_[j];   // kept separate: (dot + mu) + bu + bi, ops.py:45-47 order
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            float s = 0.f, sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float qv = q[j].v[e];
+                s = fmaf(p[j].v[e], a.item_abs ? fabsf(qv) : qv, s);
+                if constexpr (MODE == MODE_TRAIN) sq = fmaf(p[j].v[e], p[j].v[e], fmaf(qv, qv, sq));
+            }
+            s = group_sum<G>(s);
+            const float logit = ((s + mu) + bsum[j]) + bi_[j];
+            if (gl == 0 && ok[j]) {
+                if constexpr (MODE == MODE_INFER) {
+                    a.logits[k[j]] = logit;
+                } else if constexpr (MODE == MODE_TRAIN) {
+                    if (a.logits) a.logits[k[j]] = logit;
+                    const float r = a.r[k[j]];
+                    float g, l;
+                    if (a.loss == 0) {                 // ops.py:124  l2_loss(infer - rate)
+                        g = logit - r;
+                        l = 0.5f * g * g;
+                    } else {                           // ops.py:125-126 sigmoid cross-entropy
+                        g = sigmoidf_(logit) - r;
+                        l = fmaxf(logit, 0.f) - logit * r + log1pf(__expf(-fabsf(logit)));
+                    }
+                    a.g[k[j]] = g;
+                    acc[0] += l;
+                    acc[2] += g;
+                    if (a.reg_bias) sq = fmaf(bu_[j], bu_[j], fmaf(bi_[j], bi_[j], sq));
+                } else {
+                    const float r = a.r[k[j]];
+                    float inf = logit;                 // canonical infer = logits (README.md:33)
+                    if (a.loss != 0) inf = rintf(sigmoidf_(logit));   // ops.py:77-78, half-to-even
+                    const float d = inf - r;
+                    acc[0] += d * d;
+                    acc[1] += (inf == r) ? 1.f : 0.f;
+                }
+            }
+            if constexpr (MODE == MODE_TRAIN) {
+                if (ok[j]) acc[1] += 0.5f * sq;        // tf.nn.l2_loss = sum(x^2)/2
+            }
+        }
+    }
+    if (oob) atomicOr(a.err, 1);
+    if constexpr (MODE != MODE_INFER) block_sum_store<3>(acc, a.partials + (size_t)blockIdx.x * 4);
+}
+
+// ------------------------------------------------------------------------------------
+// K0  triple gather from the HBM-resident (user,item,rate) store: what
+//     ShuffleIterator.next does on the host (dataio.py:115-117), ids drawn by the host.
+__global__ __launch_bounds__(256) void k_gather_triples(GatherArgs a) {
+    bool oob = false;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.B;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        int64_t id = a.ids ? a.ids[k] : a.lo + k;
+        if ((uint64_t)id >= (uint64_t)a.N) { oob = true; id = 0; }
+        a.u[k] = a.su[id];
+        a.it[k] = a.si[id];
+        a.r[k] = a.sr[id];
+    }
+    if (oob) atomicOr(a.err, 2);
+}
+
+__global__ __launch_bounds__(256) void k_iota(int32_t* p, int64_t n) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x)
+        p[k] = (int32_t)k;
+}
+
+// ------------------------------------------------------------------------------------
+// Optimiser arithmetic, written in the operation order of the TF kernels they restate.
+struct AdamC { float alpha, b1, b2, eps, omb1, omb2; };
+
+// AdamOptimizer._apply_sparse_shared [TF1-lib]: m*b1 + g*(1-b1); v*b2 + g*g*(1-b2);
+// var - alpha*m/(sqrt(v)+eps)
+__device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float g, const AdamC& c) {
+    m = m * c.b1 + g * c.omb1;
+    v = v * c.b2 + (g * g) * c.omb2;
+    w = w - c.alpha * m / (sqrtf(v) + c.eps);
+}
+
+// ------------------------------------------------------------------------------------
+// K3  deterministic segmented reduce over a table's rows (backward of embedding_lookup:
+//     IndexedSlices -> unique + unsorted_segment_sum [TF1-lib], ops.py:143-149).
+//     Input: batch positions stably sorted by row id (ks = sorted ids, ps = positions).
+//     A lane group walks CH consecutive sorted entries and fully processes every segment
+//     that STARTS there, in batch order (fixed order -> run-to-run bit-identical, and the
+//     same order as TF-CPU's unsorted_segment_sum).
+//     per occurrence:
+//        user side: t = g_k * Qt[i_k] + lam * P[u]          Qt = |Q| if item_abs
+//        item side: t = g_k * P[u_k] * s + lam * Q[i]       s = sign(Q[i]) if item_abs
+//        bias     : t = g_k (+ lam * b[row] if reg_bias)
+//     RMODE_SCRATCH : grad row -> scratch[head position] (+ map[row] = head+1 for tf1)
+//     RMODE_ADAM    : fused lazy Adam on the row, in place
+//     RMODE_SGD     : fused var -= lr * grad, in place
+template <int G, int VEC, int RMODE>
+__global__ __launch_bounds__(256) void k_seg_reduce(RedArgs a) {
+    if (*a.err) return;                      // an out-of-range id voids the whole step
+    constexpr int GPB = 256 / G;             // groups per block
+    const int gl = threadIdx.x % G;
+    const int d0 = gl * VEC;
+    const int D = a.D;
+    const int64_t gid = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    const int64_t j0 = gid * a.chunk;
+    int64_t j1 = j0 + a.chunk;
+    if (j1 > a.B) j1 = a.B;
+    const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
+
+    for (int64_t j = j0; j < j1; ++j) {
+        const int32_t row = a.ks[j];
+        if (j > 0 && a.ks[j - 1] == row) continue;     // not a segment head
+        const size_t roff = (size_t)row * D;
+        const Frag<VEC> o = load_frag<VEC>(a.own + roff, d0, D);
+        const float ob = a.own_bias[row];
+        Frag<VEC> mrow, vrow;
+        float mb = 0.f, vb = 0.f;
+        if constexpr (RMODE == RMODE_ADAM) {           // issue early, used after the walk
+            mrow = load_frag<VEC>(a.m + roff, d0, D);
+            vrow = load_frag<VEC>(a.v + roff, d0, D);
+            mb = a.bias_m[row];
+            vb = a.bias_v[row];
+        }
+        float sg[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float x = o.v[e];
+            sg[e] = (a.side == 1 && a.item_abs) ? ((x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f)) : 1.f;
+        }
+        Frag<VEC> acc;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc.v[e] = 0.f;
+        float gb = 0.f;
+        int64_t e = j;
+        for (;;) {
+            const int32_t pos = a.ps[e];
+            const int32_t nxt = (e + 1 < a.B) ? a.ks[e + 1] : -1;
+            const float gk = a.g[pos];
+            const int32_t pid = a.other[pos];
+            const Frag<VEC> x = load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                float xv = x.v[q];
+                if (a.side == 0) { if (a.item_abs) xv = fabsf(xv); }
+                else xv = xv * sg[q];
+                acc.v[q] += gk * xv + a.lam * o.v[q];
+            }
+            gb += a.reg_bias ? (gk + a.lam * ob) : gk;
+            ++e;
+            if (nxt != row) break;
+        }
+        if constexpr (RMODE == RMODE_SCRATCH) {
+            store_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D, acc);
+            if (gl == 0) {
+                a.grad_bias[j] = gb;
+                if (a.map) a.map[row] = (int32_t)j + 1;
+            }
+        } else if constexpr (RMODE == RMODE_ADAM) {
+            if (!a.frozen_rows) {
+                Frag<VEC> w = o;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], acc.v[q], c);
+                store_frag<VEC>(a.own_w + roff, d0, D, w);
+                store_frag<VEC>(a.m + roff, d0, D, mrow);
+                store_frag<VEC>(a.v + roff, d0, D, vrow);
+            }
+            if (gl == 0 && !a.frozen_bias) {
+                float w = ob;
+                adam_sparse(w, mb, vb, gb, c);
+                a.bias_w[row] = w;
+                a.bias_m[row] = mb;
+                a.bias_v[row] = vb;
+            }
+        } else {
+            if (!a.frozen_rows) {
+                Frag<VEC> w = o;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * acc.v[q];
+                store_frag<VEC>(a.own_w + roff, d0, D, w);
+            }
+            if (gl == 0 && !a.frozen_bias) a.bias_w[row] = ob - a.lr * gb;
+        }
+        j = e - 1;                                      // skip the rest of this segment
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K5a  apply reduced gradients held in scratch (indexed by segment-head position) to the
+//      touched rows only: lazy Adam or SGD (ops.py:143-149).
+template <int G, int VEC, int OPT>
+__global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
+    if (*a.err) return;
+    constexpr int GPB = 256 / G;
+    const int gl = threadIdx.x % G;
+    const int d0 = gl * VEC;
+    const int D = a.D;
+    const int64_t gid = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    const int64_t j0 = gid * a.chunk;
+    int64_t j1 = j0 + a.chunk;
+    if (j1 > a.B) j1 = a.B;
+    const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
+    for (int64_t j = j0; j < j1; ++j) {
+        const int32_t row = a.ks[j];
+        if (j > 0 && a.ks[j - 1] == row) continue;
+        const size_t roff = (size_t)row * D;
+        if (!a.frozen_rows) {
+            const Frag<VEC> gr = load_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D);
+            Frag<VEC> w = load_frag<VEC>(a.w + roff, d0, D);
+            if constexpr (OPT == 0) {
+                Frag<VEC> mrow = load_frag<VEC>(a.m + roff, d0, D);
+                Frag<VEC> vrow = load_frag<VEC>(a.v + roff, d0, D);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], gr.v[q], c);
+                store_frag<VEC>(a.m + roff, d0, D, mrow);
+                store_frag<VEC>(a.v + roff, d0, D, vrow);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * gr.v[q];
+            }
+            store_frag<VEC>(a.w + roff, d0, D, w);
+        }
+        if (gl == 0 && !a.frozen_bias) {
+            const float gb = a.grad_bias[j];
+            float w = a.bias_w[row];
+            if constexpr (OPT == 0) {
+                float mb = a.bias_m[row], vb = a.bias_v[row];
+                adam_sparse(w, mb, vb, gb, c);
+                a.bias_m[row] = mb;
+                a.bias_v[row] = vb;
+            } else {
+                w = w - a.lr * gb;
+            }
+            a.bias_w[row] = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K5b  TF1 "sparse" Adam = dense sweep: every row decays m, v and moves;
+//      touched rows (map[row] = head+1) add their reduced gradient.  One lane group per
+//      row, consecutive groups on consecutive rows -> fully coalesced streaming.
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void k_adam_dense(DenseArgs a) {
+    if (*a.err) return;
+    constexpr int GPB = 256 / G;
+    const int gl = threadIdx.x % G;
+    const int d0 = gl * VEC;
+    const int D = a.D;
+    const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
+    for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / G; row < a.rows;
+         row += (int64_t)gridDim.x * GPB) {
+        const int32_t slot = a.map[row];
+        const size_t roff = (size_t)row * D;
+        if (!a.frozen_rows) {
+            Frag<VEC> gr;
+            if (slot) gr = load_frag<VEC>(a.grad_rows + (size_t)(slot - 1) * D, d0, D);
+            else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) gr.v[q] = 0.f;
+            }
+            Frag<VEC> w = load_frag<VEC>(a.w + roff, d0, D);
+            Frag<VEC> mrow = load_frag<VEC>(a.m + roff, d0, D);
+            Frag<VEC> vrow = load_frag<VEC>(a.v + roff, d0, D);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], gr.v[q], c);
+            store_frag<VEC>(a.w + roff, d0, D, w);
+            store_frag<VEC>(a.m + roff, d0, D, mrow);
+            store_frag<VEC>(a.v + roff, d0, D, vrow);
+        }
+        if (gl == 0 && !a.frozen_bias) {
+            const float gb = slot ? a.grad_bias[slot - 1] : 0.f;
+            float w = a.bias_w[row], mb = a.bias_m[row], vb = a.bias_v[row];
+            adam_sparse(w, mb, vb, gb, c);
+            a.bias_w[row] = w;
+            a.bias_m[row] = mb;
+            a.bias_v[row] = vb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clear_map(const int32_t* ks, int64_t B, int32_t* map,
+                                                    const int32_t* err) {
+    if (*err) return;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < B;
+         k += (int64_t)gridDim.x * blockDim.x)
+        map[ks[k]] = 0;
+}
+
+// ------------------------------------------------------------------------------------
+// K4  finalize: fixed-order reduction of the forward's per-block partials -> {data loss,
+//     regulariser, sum g}; dense update of bias_global (ApplyAdam dense kernel [TF1-lib]:
+//     m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= alpha*m/(sqrt(v)+eps); or var -= lr*g).
+__global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < a.nblk; b += 256) {
+        acc[0] += a.partials[(size_t)b * 4 + 0];
+        acc[1] += a.partials[(size_t)b * 4 + 1];
+        acc[2] += a.partials[(size_t)b * 4 + 2];
+    }
+    __shared__ float tot[3];
+    block_sum_store<3>(acc, tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.scalars[0] = tot[0];
+        a.scalars[1] = tot[1];
+        a.scalars[2] = tot[2];
+        if (a.out) { a.out[0] = tot[0]; a.out[1] = tot[1]; a.out[2] = tot[2]; }
+        if (a.update_mu && *a.err == 0) {
+            const float g = tot[2];
+            float w = *a.mu;
+            if (a.opt == 0) {
+                float m = *a.mu_m, v = *a.mu_v;
+                m += (g - m) * (1.f - a.b1);
+                v += (g * g - v) * (1.f - a.b2);
+                w -= (a.alpha * m) / (sqrtf(v) + a.eps);
+                *a.mu_m = m;
+                *a.mu_v = v;
+            } else {
+                w -= a.lr * g;
+            }
+            *a.mu = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+template <int MODE>
+static void launch_forward_mode(const FwdArgs& a, int G, int VEC, int grid, hipStream_t s) {
+#define TFR_FWD_CASE(g, v) \
+    if (G == g && VEC == v) { hipLaunchKernelGGL((k_forward<g, v, MODE>), dim3(grid), dim3(256), 0, s, a); return; }
+    TFR_FWD_CASE(4, 4) TFR_FWD_CASE(8, 4) TFR_FWD_CASE(16, 4) TFR_FWD_CASE(32, 4) TFR_FWD_CASE(64, 4)
+    TFR_FWD_CASE(4, 1) TFR_FWD_CASE(8, 1) TFR_FWD_CASE(16, 1) TFR_FWD_CASE(32, 1) TFR_FWD_CASE(64, 1)
+#undef TFR_FWD_CASE
+}
+
+int forward_grid(int64_t B, int G) {
+    const int64_t per_block = 4 * (64 / G) * 4;         // waves * SPW * UNR
+    int64_t nb = (B + per_block - 1) / per_block;
+    if (nb > 2048) nb = 2048;                            // 256 CUs x 8 blocks, then grid-stride
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s) {
+    if (mode == MODE_INFER) launch_forward_mode<MODE_INFER>(a, G, VEC, grid, s);
+    else if (mode == MODE_TRAIN) launch_forward_mode<MODE_TRAIN>(a, G, VEC, grid, s);
+    else launch_forward_mode<MODE_EVAL>(a, G, VEC, grid, s);
+}
+
+static int chunk_grid(int64_t B, int chunk, int G) {
+    const int64_t groups = (B + chunk - 1) / chunk;
+    const int gpb = 256 / G;
+    int64_t nb = (groups + gpb - 1) / gpb;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+void launch_seg_reduce(const RedArgs& a, int rmode, int G, int VEC, hipStream_t s) {
+    const int grid = chunk_grid(a.B, a.chunk, G);
+#define TFR_RED_CASE(g, v)                                                                             \
+    if (G == g && VEC == v) {                                                                          \
+        if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), dim3(grid), dim3(256), 0, s, a); \
+        else if (rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM>), dim3(grid), dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD>), dim3(grid), dim3(256), 0, s, a);      \
+        return;                                                                                        \
+    }
+    TFR_RED_CASE(4, 4) TFR_RED_CASE(8, 4) TFR_RED_CASE(16, 4) TFR_RED_CASE(32, 4) TFR_RED_CASE(64, 4)
+    TFR_RED_CASE(4, 1) TFR_RED_CASE(8, 1) TFR_RED_CASE(16, 1) TFR_RED_CASE(32, 1) TFR_RED_CASE(64, 1)
+#undef TFR_RED_CASE
+}
+
+void launch_apply_rows(const ApplyArgs& a, int opt, int G, int VEC, hipStream_t s) {
+    const int grid = chunk_grid(a.B, a.chunk, G);
+#define TFR_APP_CASE(g, v)                                                                        \
+    if (G == g && VEC == v) {                                                                     \
+        if (opt == 0) hipLaunchKernelGGL((k_apply_rows<g, v, 0>), dim3(grid), dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((k_apply_rows<g, v, 1>), dim3(grid), dim3(256), 0, s, a);         \
+        return;                                                                                   \
+    }
+    TFR_APP_CASE(4, 4) TFR_APP_CASE(8, 4) TFR_APP_CASE(16, 4) TFR_APP_CASE(32, 4) TFR_APP_CASE(64, 4)
+    TFR_APP_CASE(4, 1) TFR_APP_CASE(8, 1) TFR_APP_CASE(16, 1) TFR_APP_CASE(32, 1) TFR_APP_CASE(64, 1)
+#undef TFR_APP_CASE
+}
+
+void launch_adam_dense(const DenseArgs& a, int G, int VEC, hipStream_t s) {
+    const int gpb = 256 / G;
+    int64_t nb = (a.rows + gpb - 1) / gpb;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+#define TFR_DEN_CASE(g, v) \
+    if (G == g && VEC == v) { hipLaunchKernelGGL((k_adam_dense<g, v>), dim3((int)nb), dim3(256), 0, s, a); return; }
+    TFR_DEN_CASE(4, 4) TFR_DEN_CASE(8, 4) TFR_DEN_CASE(16, 4) TFR_DEN_CASE(32, 4) TFR_DEN_CASE(64, 4)
+    TFR_DEN_CASE(4, 1) TFR_DEN_CASE(8, 1) TFR_DEN_CASE(16, 1) TFR_DEN_CASE(32, 1) TFR_DEN_CASE(64, 1)
+#undef TFR_DEN_CASE
+}
+
+static int flat_grid(int64_t n) {
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+void launch_clear_map(const int32_t* ks, int64_t B, int32_t* map, const int32_t* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_clear_map, dim3(flat_grid(B)), dim3(256), 0, s, ks, B, map, err);
+}
+
+void launch_gather(const GatherArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_triples, dim3(flat_grid(a.B)), dim3(256), 0, s, a);
+}
+
+void launch_iota(int32_t* p, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_iota, dim3(flat_grid(n)), dim3(256), 0, s, p, n);
+}
+
+void launch_finalize(const FinArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, a);
+}
+
+}  // namespace tfr

@@ -1,0 +1,201 @@
+"""SvdModel: thin object wrapper over the C-ABI handle (include/tfrecomm.h).
+
+Holds no arithmetic: every number comes from the HIP kernels.  The reference-shaped
+surface (``ops.inference_svd`` / ``ops.optimization`` / ``Session.run``) in ``ops.py``
+and ``graph.py`` is built on this class.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class SvdModel:
+    """The five trainables of ops.py:8-12,29-32 (+ optimiser slots) resident in HBM."""
+
+    def __init__(self, user_num, item_num, dim, *, loss="mse", item_abs=False, reg_bias=False,
+                 optimizer="adam", adam_mode="tf1", lr=1e-3, reg=0.05, beta1=0.9, beta2=0.999,
+                 eps=1e-8, device=0):
+        lib = L.load()
+        o = L.TfrOpts()
+        lib.tfr_default_opts(C.byref(o))
+        o.loss = L.LOSS[loss]
+        o.item_abs = int(bool(item_abs))
+        o.reg_bias = int(bool(reg_bias))
+        o.optimizer = L.OPTIMIZER[optimizer]
+        o.adam_mode = L.ADAM_MODE[adam_mode]
+        o.device = int(device)
+        o.lr, o.reg, o.beta1, o.beta2, o.eps = lr, reg, beta1, beta2, eps
+        self._h = L._p()
+        self._lib = lib
+        self.user_num, self.item_num, self.dim = int(user_num), int(item_num), int(dim)
+        self.loss, self.optimizer, self.adam_mode = loss, optimizer, adam_mode
+        self.item_abs, self.reg_bias = bool(item_abs), bool(reg_bias)
+        self.device = int(device)
+        L.check(lib.tfr_create(C.byref(self._h), self.user_num, self.item_num, self.dim, C.byref(o)))
+
+    # -- lifetime -----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.tfr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- variables ----------------------------------------------------------------
+    def _count(self, which):
+        t = which & 7
+        return {L.MU: 1, L.BU: self.user_num, L.BI: self.item_num,
+                L.P: self.user_num * self.dim, L.Q: self.item_num * self.dim}[t]
+
+    def _shape(self, which):
+        t = which & 7
+        return {L.MU: (), L.BU: (self.user_num,), L.BI: (self.item_num,),
+                L.P: (self.user_num, self.dim), L.Q: (self.item_num, self.dim)}[t]
+
+    def set_table(self, which, values):
+        a = L.as_f32(values).reshape(-1)
+        L.check(self._lib.tfr_set_table(self._h, which, L.ptr_f32(a), a.size))
+
+    def get_table(self, which):
+        out = np.empty(self._count(which), np.float32)
+        L.check(self._lib.tfr_get_table(self._h, which, L.ptr_f32(out), out.size))
+        return out.reshape(self._shape(which))
+
+    def set_tables(self, mu, bu, bi, P, Q):
+        for which, val in ((L.MU, mu), (L.BU, bu), (L.BI, bi), (L.P, P), (L.Q, Q)):
+            self.set_table(which, val)
+
+    def tables(self):
+        return {w: self.get_table(w) for w in (L.MU, L.BU, L.BI, L.P, L.Q)}
+
+    def set_frozen(self, mask):
+        L.check(self._lib.tfr_set_frozen(self._h, int(mask)))
+
+    def set_hyper(self, lr, reg):
+        L.check(self._lib.tfr_set_hyper(self._h, lr, reg))
+
+    @property
+    def step(self):
+        return self.get_step()[0]
+
+    def get_step(self):
+        s, a, b = C.c_int64(), C.c_float(), C.c_float()
+        L.check(self._lib.tfr_get_step(self._h, C.byref(s), C.byref(a), C.byref(b)))
+        return s.value, a.value, b.value
+
+    def set_step(self, step, beta1_power, beta2_power):
+        L.check(self._lib.tfr_set_step(self._h, int(step), beta1_power, beta2_power))
+
+    # -- forward / train ----------------------------------------------------------
+    def forward(self, users, items):
+        u, i = L.as_i32(users, "user ids"), L.as_i32(items, "item ids")
+        if u.shape != i.shape or u.ndim != 1:
+            raise ValueError("user and item batches must be 1-D and of equal length")
+        out = np.empty(u.size, np.float32)
+        L.check(self._lib.tfr_forward(self._h, L.ptr_i32(u), L.ptr_i32(i), u.size, L.ptr_f32(out)))
+        return out
+
+    def eval(self, users, items, rates):
+        u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
+        if not (u.shape == i.shape == r.shape) or u.ndim != 1:
+            raise ValueError("batches must be 1-D and of equal length")
+        sse, neq = C.c_double(), C.c_int64()
+        L.check(self._lib.tfr_eval(self._h, L.ptr_i32(u), L.ptr_i32(i), L.ptr_f32(r), u.size,
+                                   C.byref(sse), C.byref(neq)))
+        return sse.value, neq.value
+
+    def train_step(self, users, items, rates, want_logits=True):
+        u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
+        if not (u.shape == i.shape == r.shape) or u.ndim != 1:
+            raise ValueError("batches must be 1-D and of equal length")
+        logits = np.empty(u.size, np.float32) if want_logits else None
+        loss, reg = C.c_float(), C.c_float()
+        L.check(self._lib.tfr_train_step(self._h, L.ptr_i32(u), L.ptr_i32(i), L.ptr_f32(r), u.size,
+                                         L.ptr_f32(logits) if want_logits else None,
+                                         C.byref(loss), C.byref(reg)))
+        return logits, loss.value, reg.value
+
+    # -- resident store -----------------------------------------------------------
+    def upload_triples(self, users, items, rates):
+        u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
+        L.check(self._lib.tfr_upload_triples(self._h, L.ptr_i32(u), L.ptr_i32(i), L.ptr_f32(r), u.size))
+
+    def train_steps_resident(self, ids, batch, want_loss=True):
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64)).reshape(-1)
+        if ids.size % batch:
+            raise ValueError("ids length must be a multiple of batch")
+        n = ids.size // batch
+        loss = np.empty(n, np.float32) if want_loss else None
+        L.check(self._lib.tfr_train_steps_resident(self._h, L.ptr_i64(ids), batch, n,
+                                                   L.ptr_f32(loss) if want_loss else None))
+        return loss
+
+    def stage_ids(self, ids):
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64)).reshape(-1)
+        L.check(self._lib.tfr_stage_ids(self._h, L.ptr_i64(ids), ids.size))
+
+    def train_steps_staged(self, first_step, batch, nsteps, want_loss=False):
+        loss = np.empty(nsteps, np.float32) if want_loss else None
+        L.check(self._lib.tfr_train_steps_staged(self._h, first_step, batch, nsteps,
+                                                 L.ptr_f32(loss) if want_loss else None))
+        return loss
+
+    def forward_resident(self, lo, hi):
+        out = np.empty(hi - lo, np.float32)
+        L.check(self._lib.tfr_forward_resident(self._h, lo, hi, L.ptr_f32(out)))
+        return out
+
+    def sort_segments(self, side, ids):
+        a = L.as_i32(ids)
+        ks, ps = np.empty(a.size, np.int32), np.empty(a.size, np.int32)
+        L.check(self._lib.tfr_sort_segments(self._h, side, L.ptr_i32(a), a.size, L.ptr_i32(ks), L.ptr_i32(ps)))
+        return ks, ps
+
+    # -- device-pointer plumbing --------------------------------------------------
+    def forward_dev(self, d_user, d_item, batch, d_logits):
+        L.check(self._lib.tfr_forward_dev(self._h, d_user, d_item, batch, d_logits))
+
+    def train_step_dev(self, d_user, d_item, d_rate, batch, d_logits=None):
+        L.check(self._lib.tfr_train_step_dev(self._h, d_user, d_item, d_rate, batch, d_logits))
+
+    def table_devptr(self, which):
+        p, n = L._p(), C.c_int64()
+        L.check(self._lib.tfr_table_devptr(self._h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_stream(self, stream_ptr):
+        L.check(self._lib.tfr_set_stream(self._h, stream_ptr))
+
+    def get_stream(self):
+        p = L._p()
+        L.check(self._lib.tfr_get_stream(self._h, C.byref(p)))
+        return p.value
+
+    def sync(self):
+        L.check(self._lib.tfr_sync(self._h))
+
+    # -- per-kernel HIP-event timing ----------------------------------------------
+    def profile(self, enable=True):
+        L.check(self._lib.tfr_profile(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        out = {}
+        for k, name in enumerate(L.KERNEL_NAMES):
+            ms, n = C.c_double(), C.c_int64()
+            L.check(self._lib.tfr_profile_read(self._h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
