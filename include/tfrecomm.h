@@ -77,6 +77,13 @@ int tfr_create(tfr_model** out, int64_t user_num, int64_t item_num, int32_t dim,
 int tfr_destroy(tfr_model* m);
 void tfr_default_opts(tfr_opts* opts);
 
+/* tf.global_variables_initializer() (svd_train_val.py:53,56) on the device: user/item features
+ * ~ truncated normal(stddev 0.02), biases ~ truncated normal(stddev 1) (ops.py:9-12,29-32),
+ * bias_global ~ U(-sqrt 3, sqrt 3) (TF's default glorot-uniform for a scalar); Adam slots,
+ * global_step and the beta powers are reset.  The stream differs from TensorFlow's Philox,
+ * so initial values are not a parity target. */
+int tfr_init_tables(tfr_model* m, uint64_t seed, float feature_stddev, float bias_stddev);
+
 /* ---- variables: tf.Variable.load / .eval and tf.train.Saver (svd_train_val.py:54,197-198) */
 int tfr_set_table(tfr_model* m, int32_t which, const float* host, int64_t n);
 int tfr_get_table(tfr_model* m, int32_t which, float* host, int64_t n);
@@ -108,6 +115,10 @@ int tfr_train_step(tfr_model* m, const int32_t* user, const int32_t* item, const
  *      (dataio.py:98-103,114-117) kept in HBM; the host still draws the ids. */
 int tfr_upload_triples(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
                        int64_t n);
+/* same, but the three columns are already in HBM (device pointers, borrowed: the caller keeps
+ * them alive until the next upload / set / destroy). */
+int tfr_set_triples_dev(tfr_model* m, const int32_t* d_user, const int32_t* d_item,
+                        const float* d_rate, int64_t n);
 /* ids[step*batch + k] index the store: nsteps minibatches in one call.  loss_out[nsteps]
  * (data term per step) may be NULL (then the call does not synchronise). */
 int tfr_train_steps_resident(tfr_model* m, const int64_t* ids, int64_t batch, int32_t nsteps,

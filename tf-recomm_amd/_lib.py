@@ -52,6 +52,8 @@ SIGNATURES = {
     "tfr_create": (C.c_int, [C.POINTER(_p), C.c_int64, C.c_int64, C.c_int32, C.POINTER(TfrOpts)]),
     "tfr_destroy": (C.c_int, [_p]),
     "tfr_default_opts": (None, [C.POINTER(TfrOpts)]),
+    "tfr_init_tables": (C.c_int, [_p, C.c_uint64, C.c_float, C.c_float]),
+    "tfr_set_triples_dev": (C.c_int, [_p, _p, _p, _p, C.c_int64]),
     "tfr_set_table": (C.c_int, [_p, C.c_int32, _f32p, C.c_int64]),
     "tfr_get_table": (C.c_int, [_p, C.c_int32, _f32p, C.c_int64]),
     "tfr_set_frozen": (C.c_int, [_p, C.c_uint32]),

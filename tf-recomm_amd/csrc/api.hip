@@ -57,6 +57,8 @@ struct tfr_model {
     int32_t *iota = nullptr, *ks_u = nullptr, *ps_u = nullptr, *ks_i = nullptr, *ps_i = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    int32_t *lrank_u = nullptr, *lrank_i = nullptr, *hist_u = nullptr, *hist_i = nullptr;   // csort
+    int32_t *offs_u = nullptr, *offs_i = nullptr, *binbase_u = nullptr, *binbase_i = nullptr;
     float *gq = nullptr, *gp = nullptr, *gbq = nullptr, *gbp = nullptr;
     int32_t *map_u = nullptr, *map_i = nullptr;
     float* partials = nullptr;
@@ -68,6 +70,7 @@ struct tfr_model {
     int32_t *su = nullptr, *si = nullptr;
     float* sr = nullptr;
     int64_t N = 0;
+    bool store_owned = false;
     int64_t* d_ids = nullptr;
     int64_t n_ids = 0;
     // profiling
@@ -134,7 +137,10 @@ static void free_workspace(tfr_model* m) {
     dfree(m->d_u); dfree(m->d_i); dfree(m->d_r); dfree(m->d_logits); dfree(m->d_g);
     dfree(m->iota); dfree(m->ks_u); dfree(m->ps_u); dfree(m->ks_i); dfree(m->ps_i);
     dfree(m->sort_tmp); dfree(m->gq); dfree(m->gp); dfree(m->gbq); dfree(m->gbp);
-    dfree(m->partials);
+    dfree(m->partials); dfree(m->lrank_u); dfree(m->lrank_i); dfree(m->hist_u); dfree(m->hist_i);
+    dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
+    m->lrank_u = m->lrank_i = m->hist_u = m->hist_i = nullptr;
+    m->offs_u = m->offs_i = m->binbase_u = m->binbase_i = nullptr;
     m->d_u = m->d_i = nullptr; m->d_r = m->d_logits = m->d_g = nullptr;
     m->iota = m->ks_u = m->ps_u = m->ks_i = m->ps_i = nullptr;
     m->sort_tmp = nullptr; m->gq = m->gp = m->gbq = m->gbp = nullptr; m->partials = nullptr;
@@ -166,12 +172,25 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     tb = 2 * tb + (1 << 20);          // head-room: smaller batches may pick another rocPRIM path
     m->sort_tmp_bytes = tb;
     HIPCHK(hipMalloc(&m->sort_tmp, tb));
-    if ((rc = dmalloc(&m->gq, (size_t)cap * m->D))) return rc;
+    const bool tf1_ws = m->o.optimizer == TFR_OPT_ADAM && m->o.adam_mode == TFR_ADAM_TF1;
+    // non-tf1: second half of gq parks the pieces of split user runs
+    if ((rc = dmalloc(&m->gq, (size_t)cap * m->D * (tf1_ws ? 1 : 2)))) return rc;
     if ((rc = dmalloc(&m->gbq, cap))) return rc;
     if ((rc = dmalloc(&m->gbp, cap))) return rc;
-    if (m->o.optimizer == TFR_OPT_ADAM && m->o.adam_mode == TFR_ADAM_TF1)
+    if (tf1_ws)
         if ((rc = dmalloc(&m->gp, (size_t)cap * m->D))) return rc;
     if ((rc = dmalloc(&m->partials, (size_t)2048 * 4))) return rc;
+    if ((1 << (m->bits_u > m->bits_i ? m->bits_u : m->bits_i)) <= CSORT_MAX_BINS) {
+        const size_t ntiles = (size_t)(cap + CSORT_TILE - 1) / CSORT_TILE;
+        if ((rc = dmalloc(&m->lrank_u, cap))) return rc;
+        if ((rc = dmalloc(&m->lrank_i, cap))) return rc;
+        if ((rc = dmalloc(&m->hist_u, ((size_t)1 << m->bits_u) * ntiles))) return rc;
+        if ((rc = dmalloc(&m->hist_i, ((size_t)1 << m->bits_i) * ntiles))) return rc;
+        if ((rc = dmalloc(&m->offs_u, ((size_t)1 << m->bits_u) * ntiles))) return rc;
+        if ((rc = dmalloc(&m->offs_i, ((size_t)1 << m->bits_i) * ntiles))) return rc;
+        if ((rc = dmalloc(&m->binbase_u, (size_t)1 << m->bits_u))) return rc;
+        if ((rc = dmalloc(&m->binbase_i, (size_t)1 << m->bits_i))) return rc;
+    }
     launch_iota(m->iota, cap, m->stream);
     HIPCHK(hipGetLastError());
     m->cap = cap;
@@ -243,7 +262,8 @@ int tfr_destroy(tfr_model* m) {
     free_workspace(m);
     for (int t = 0; t < 5; ++t) { dfree(m->w[t]); dfree(m->m[t]); dfree(m->v[t]); }
     dfree(m->map_u); dfree(m->map_i); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
-    dfree(m->su); dfree(m->si); dfree(m->sr); dfree(m->d_ids);
+    if (m->store_owned) { dfree(m->su); dfree(m->si); dfree(m->sr); }
+    dfree(m->d_ids);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
     return TFR_OK;
@@ -456,12 +476,18 @@ int tfr_profile_read(tfr_model* m, int32_t kernel, double* total_ms, int64_t* la
 // ---------------------------------------------------------------------------------------
 // forward on device-resident ids
 static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t* di, const float* dr,
-                       int64_t B, float* d_logits, float* d_g, int* nblk_out) {
+                       int64_t B, float* d_logits, float* d_g, int* nblk_out,
+                       const int64_t* d_store_ids = nullptr) {
     FwdArgs a;
+    memset(&a, 0, sizeof(a));
     a.P = m->w[TFR_P]; a.Q = m->w[TFR_Q]; a.bu = m->w[TFR_BU]; a.bi = m->w[TFR_BI]; a.mu = m->w[TFR_MU];
     a.u = du; a.it = di; a.r = dr;
     a.logits = d_logits; a.g = d_g; a.partials = m->partials; a.err = m->d_err;
-    a.B = B; a.U = m->U; a.I = m->I;
+    a.B = B; a.U = m->U; a.I = m->I; a.N = m->N;
+    if (d_store_ids) {                 // fused gather from the resident store
+        a.ids = d_store_ids; a.su = m->su; a.si = m->si; a.sr = m->sr;
+        a.u_out = m->d_u; a.it_out = m->d_i;
+    }
     a.D = m->D; a.loss = m->o.loss; a.item_abs = m->o.item_abs; a.reg_bias = m->o.reg_bias;
     const int grid = forward_grid(B, m->G);
     if (nblk_out) *nblk_out = grid;
@@ -473,9 +499,31 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
     return TFR_OK;
 }
 
-// one minibatch on device-resident (u, i, r); out3 = optional device {loss, reg, sum_g} slot
+// stable sort of batch positions by user id and by item id
+static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int64_t B) {
+    Prof p(m, TFR_K_SORT);
+    if (m->lrank_u && csort_eligible(B, m->bits_u, m->bits_i)) {
+        CSortArgs c;
+        c.keys[0] = du; c.keys[1] = di;
+        c.ks[0] = m->ks_u; c.ks[1] = m->ks_i; c.ps[0] = m->ps_u; c.ps[1] = m->ps_i;
+        c.lrank[0] = m->lrank_u; c.lrank[1] = m->lrank_i; c.hist[0] = m->hist_u; c.hist[1] = m->hist_i;
+        c.offs[0] = m->offs_u; c.offs[1] = m->offs_i; c.binbase[0] = m->binbase_u; c.binbase[1] = m->binbase_i;
+        c.nbins[0] = 1 << m->bits_u; c.nbins[1] = 1 << m->bits_i;
+        c.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+        c.B = B;
+        launch_csort(c, m->stream);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, di, m->ks_i, m->iota, m->ps_i, B, m->bits_i, m->stream));
+        HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, du, m->ks_u, m->iota, m->ps_u, B, m->bits_u, m->stream));
+    }
+    return TFR_OK;
+}
+
+// one minibatch on device-resident (u, i, r) - or, with d_store_ids, on rows of the resident
+// store gathered inside the forward kernel; out3 = optional device {loss, reg, sum_g} slot
 static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
-                          float* d_logits, float* out3) {
+                          float* d_logits, float* out3, const int64_t* d_store_ids = nullptr) {
     const tfr_opts& o = m->o;
     const bool adam = o.optimizer == TFR_OPT_ADAM;
     const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
@@ -484,17 +532,13 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     int nblk = 0;
     hipStream_t s = m->stream;
     if (B > 0) {
-        int rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk);
+        int rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk, d_store_ids);
         if (rc) return rc;
-        {
-            Prof p(m, TFR_K_SORT);
-            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, di, m->ks_i, m->iota, m->ps_i, B, m->bits_i, s));
-            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, du, m->ks_u, m->iota, m->ps_u, B, m->bits_u, s));
-        }
+        if (d_store_ids) { du = m->d_u; di = m->d_i; }
+        if ((rc = sort_columns(m, du, di, B))) return rc;
         RedArgs r;
         memset(&r, 0, sizeof(r));
         r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
-        r.chunk = 4;
         r.item_abs = o.item_abs; r.reg_bias = o.reg_bias;
         r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
         // item side -> scratch (reads the pre-update user rows)
@@ -503,11 +547,6 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         ri.ks = m->ks_i; ri.ps = m->ps_i; ri.other = du;
         ri.own = m->w[TFR_Q]; ri.partner = m->w[TFR_P]; ri.own_bias = m->w[TFR_BI];
         ri.grad_rows = m->gq; ri.grad_bias = m->gbq; ri.map = tf1 ? m->map_i : nullptr;
-        {
-            Prof p(m, TFR_K_REDUCE_ITEM);
-            launch_seg_reduce(ri, RMODE_SCRATCH, m->G, m->VEC, s);
-        }
-        HIPCHK(hipGetLastError());
         // user side: fused update (lazy Adam / SGD) or scratch (TF1 Adam)
         RedArgs ru = r;
         ru.side = 0;
@@ -515,52 +554,77 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         ru.own = m->w[TFR_P]; ru.partner = m->w[TFR_Q]; ru.own_bias = m->w[TFR_BU];
         ru.own_w = m->w[TFR_P]; ru.m = m->m[TFR_P]; ru.v = m->v[TFR_P];
         ru.bias_w = m->w[TFR_BU]; ru.bias_m = m->m[TFR_BU]; ru.bias_v = m->v[TFR_BU];
-        ru.grad_rows = m->gp; ru.grad_bias = m->gbp; ru.map = tf1 ? m->map_u : nullptr;
+        ru.grad_bias = m->gbp; ru.map = tf1 ? m->map_u : nullptr;
         ru.frozen_rows = (m->frozen >> TFR_P) & 1; ru.frozen_bias = (m->frozen >> TFR_BU) & 1;
-        {
-            Prof p(m, TFR_K_REDUCE_USER);
-            launch_seg_reduce(ru, tf1 ? RMODE_SCRATCH : (adam ? RMODE_ADAM : RMODE_SGD), m->G, m->VEC, s);
-        }
-        HIPCHK(hipGetLastError());
-        if (!tf1) {
-            ApplyArgs ap;
-            memset(&ap, 0, sizeof(ap));
-            ap.ks = m->ks_i; ap.grad_rows = m->gq; ap.grad_bias = m->gbq;
-            ap.w = m->w[TFR_Q]; ap.m = m->m[TFR_Q]; ap.v = m->v[TFR_Q];
-            ap.bias_w = m->w[TFR_BI]; ap.bias_m = m->m[TFR_BI]; ap.bias_v = m->v[TFR_BI];
-            ap.err = m->d_err; ap.B = B; ap.D = m->D; ap.chunk = 4;
-            ap.frozen_rows = (m->frozen >> TFR_Q) & 1; ap.frozen_bias = (m->frozen >> TFR_BI) & 1;
-            ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
+        if (tf1) {
+            // both sides only read the tables: one launch
+            ru.grad_rows = m->gp;
+            RedPair pr;
+            pr.a[0] = ri; pr.a[1] = ru;
+            Prof p(m, TFR_K_REDUCE_ITEM);
+            launch_seg_reduce(pr, 2, RMODE_SCRATCH, m->G, m->VEC, s);
+        } else {
+            // the user side updates P in place, so the item side (which reads P) goes first.
+            // Pieces of split user runs are parked in the second half of gq (2*cap rows).
+            ru.grad_rows = m->gq + (size_t)m->cap * m->D;
+            RedPair pr;
+            pr.a[0] = ri;
             {
-                Prof p(m, TFR_K_APPLY);
-                launch_apply_rows(ap, adam ? 0 : 1, m->G, m->VEC, s);
+                Prof p(m, TFR_K_REDUCE_ITEM);
+                launch_seg_reduce(pr, 1, RMODE_SCRATCH, m->G, m->VEC, s);
             }
             HIPCHK(hipGetLastError());
+            pr.a[0] = ru;
+            {
+                Prof p(m, TFR_K_REDUCE_USER);
+                launch_seg_reduce(pr, 1, adam ? RMODE_ADAM : RMODE_SGD, m->G, m->VEC, s);
+            }
+            HIPCHK(hipGetLastError());
+            ApplyArgs ap;
+            memset(&ap, 0, sizeof(ap));
+            ap.err = m->d_err; ap.B = B; ap.D = m->D;
+            ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
+            ApplyPair app;
+            app.a[0] = ap;                     // item rows: every run
+            app.a[0].ks = m->ks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
+            app.a[0].w = m->w[TFR_Q]; app.a[0].m = m->m[TFR_Q]; app.a[0].v = m->v[TFR_Q];
+            app.a[0].bias_w = m->w[TFR_BI]; app.a[0].bias_m = m->m[TFR_BI]; app.a[0].bias_v = m->v[TFR_BI];
+            app.a[0].frozen_rows = (m->frozen >> TFR_Q) & 1; app.a[0].frozen_bias = (m->frozen >> TFR_BI) & 1;
+            app.a[1] = ap;                     // user rows: only the runs cut into several pieces
+            app.a[1].only_split = 1;
+            app.a[1].ks = m->ks_u; app.a[1].grad_rows = ru.grad_rows; app.a[1].grad_bias = m->gbp;
+            app.a[1].w = m->w[TFR_P]; app.a[1].m = m->m[TFR_P]; app.a[1].v = m->v[TFR_P];
+            app.a[1].bias_w = m->w[TFR_BU]; app.a[1].bias_m = m->m[TFR_BU]; app.a[1].bias_v = m->v[TFR_BU];
+            app.a[1].frozen_rows = ru.frozen_rows; app.a[1].frozen_bias = ru.frozen_bias;
+            {
+                Prof p(m, TFR_K_APPLY);
+                launch_apply_rows(app, 2, adam ? 0 : 1, m->G, m->VEC, s);
+            }
         }
+        HIPCHK(hipGetLastError());
     }
     if (tf1) {
-        // dense sweeps: every row of every unfrozen table moves
+        // dense sweeps: every row of every unfrozen table moves; one launch
         Prof p(m, TFR_K_APPLY);
         DenseArgs d;
         memset(&d, 0, sizeof(d));
-        d.err = m->d_err; d.D = m->D;
+        d.err = m->d_err; d.D = m->D; d.B = B;
         d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps;
-        DenseArgs dp = d;
-        dp.map = m->map_u; dp.grad_rows = m->gp; dp.grad_bias = m->gbp; dp.rows = m->U;
-        dp.w = m->w[TFR_P]; dp.m = m->m[TFR_P]; dp.v = m->v[TFR_P];
-        dp.bias_w = m->w[TFR_BU]; dp.bias_m = m->m[TFR_BU]; dp.bias_v = m->v[TFR_BU];
-        dp.frozen_rows = (m->frozen >> TFR_P) & 1; dp.frozen_bias = (m->frozen >> TFR_BU) & 1;
-        if (!(dp.frozen_rows && dp.frozen_bias)) launch_adam_dense(dp, m->G, m->VEC, s);
-        DenseArgs dq = d;
-        dq.map = m->map_i; dq.grad_rows = m->gq; dq.grad_bias = m->gbq; dq.rows = m->I;
-        dq.w = m->w[TFR_Q]; dq.m = m->m[TFR_Q]; dq.v = m->v[TFR_Q];
-        dq.bias_w = m->w[TFR_BI]; dq.bias_m = m->m[TFR_BI]; dq.bias_v = m->v[TFR_BI];
-        dq.frozen_rows = (m->frozen >> TFR_Q) & 1; dq.frozen_bias = (m->frozen >> TFR_BI) & 1;
-        if (!(dq.frozen_rows && dq.frozen_bias)) launch_adam_dense(dq, m->G, m->VEC, s);
-        if (B > 0) {
-            launch_clear_map(m->ks_u, B, m->map_u, m->d_err, s);
-            launch_clear_map(m->ks_i, B, m->map_i, m->d_err, s);
-        }
+        DensePair dp;
+        dp.a[0] = d;
+        dp.a[0].map = m->map_u; dp.a[0].ks = m->ks_u; dp.a[0].grad_rows = m->gp; dp.a[0].grad_bias = m->gbp;
+        dp.a[0].rows = m->U;
+        dp.a[0].w = m->w[TFR_P]; dp.a[0].m = m->m[TFR_P]; dp.a[0].v = m->v[TFR_P];
+        dp.a[0].bias_w = m->w[TFR_BU]; dp.a[0].bias_m = m->m[TFR_BU]; dp.a[0].bias_v = m->v[TFR_BU];
+        dp.a[0].frozen_rows = (m->frozen >> TFR_P) & 1; dp.a[0].frozen_bias = (m->frozen >> TFR_BU) & 1;
+        dp.a[1] = d;
+        dp.a[1].map = m->map_i; dp.a[1].ks = m->ks_i; dp.a[1].grad_rows = m->gq; dp.a[1].grad_bias = m->gbq;
+        dp.a[1].rows = m->I;
+        dp.a[1].w = m->w[TFR_Q]; dp.a[1].m = m->m[TFR_Q]; dp.a[1].v = m->v[TFR_Q];
+        dp.a[1].bias_w = m->w[TFR_BI]; dp.a[1].bias_m = m->m[TFR_BI]; dp.a[1].bias_v = m->v[TFR_BI];
+        dp.a[1].frozen_rows = (m->frozen >> TFR_Q) & 1; dp.a[1].frozen_bias = (m->frozen >> TFR_BI) & 1;
+        // the sweep also consumes (clears) the row->slot maps, so it always runs on both tables
+        launch_adam_dense(dp, 2, m->G, m->VEC, s);
         HIPCHK(hipGetLastError());
     }
     FinArgs f;
@@ -695,8 +759,9 @@ int tfr_upload_triples(tfr_model* m, const int32_t* u, const int32_t* i, const f
     MODEL_ENTER(m);
     if (N < 1 || !u || !i || !r) return fail(TFR_ERR_ARG, "upload_triples: need n >= 1 and non-null columns");
     HIPCHK(hipStreamSynchronize(m->stream));
-    dfree(m->su); dfree(m->si); dfree(m->sr);
+    if (m->store_owned) { dfree(m->su); dfree(m->si); dfree(m->sr); }
     m->su = m->si = nullptr; m->sr = nullptr; m->N = 0;
+    m->store_owned = true;
     int rc;
     if ((rc = dmalloc(&m->su, (size_t)N))) return rc;
     if ((rc = dmalloc(&m->si, (size_t)N))) return rc;
@@ -706,6 +771,39 @@ int tfr_upload_triples(tfr_model* m, const int32_t* u, const int32_t* i, const f
     HIPCHK(hipMemcpyAsync(m->sr, r, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     m->N = N;
+    return TFR_OK;
+}
+
+int tfr_set_triples_dev(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t N) {
+    MODEL_ENTER(m);
+    if (N < 1 || !du || !di || !dr) return fail(TFR_ERR_ARG, "set_triples_dev: need n >= 1 and non-null columns");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->store_owned) { dfree(m->su); dfree(m->si); dfree(m->sr); }
+    m->store_owned = false;
+    m->su = const_cast<int32_t*>(du);
+    m->si = const_cast<int32_t*>(di);
+    m->sr = const_cast<float*>(dr);
+    m->N = N;
+    return TFR_OK;
+}
+
+int tfr_init_tables(tfr_model* m, uint64_t seed, float fstd, float bstd) {
+    MODEL_ENTER(m);
+    hipStream_t s = m->stream;
+    launch_init_trunc_normal(m->w[TFR_P], m->n[TFR_P], fstd, seed * 4 + 0, s);
+    launch_init_trunc_normal(m->w[TFR_Q], m->n[TFR_Q], fstd, seed * 4 + 1, s);
+    launch_init_trunc_normal(m->w[TFR_BU], m->n[TFR_BU], bstd, seed * 4 + 2, s);
+    launch_init_trunc_normal(m->w[TFR_BI], m->n[TFR_BI], bstd, seed * 4 + 3, s);
+    launch_init_uniform_scalar(m->w[TFR_MU], -1.7320508f, 1.7320508f, seed, s);
+    HIPCHK(hipGetLastError());
+    for (int t = 0; t < 5; ++t) {
+        if (m->m[t]) HIPCHK(hipMemsetAsync(m->m[t], 0, (size_t)m->n[t] * 4, s));
+        if (m->v[t]) HIPCHK(hipMemsetAsync(m->v[t], 0, (size_t)m->n[t] * 4, s));
+    }
+    m->step = 0;
+    m->b1p = m->o.beta1;
+    m->b2p = m->o.beta2;
+    HIPCHK(hipStreamSynchronize(s));
     return TFR_OK;
 }
 
@@ -743,9 +841,9 @@ static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nst
     const int64_t step0 = m->step;
     const float b1p0 = m->b1p, b2p0 = m->b2p;
     for (int32_t s = 0; s < nsteps; ++s) {
-        if ((rc = gather_batch(m, m->d_ids + (first_step + s) * B, 0, B))) return rc;
         if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr,
-                                 loss_out ? m->step_out + (size_t)s * 4 : nullptr)))
+                                 loss_out ? m->step_out + (size_t)s * 4 : nullptr,
+                                 m->d_ids + (first_step + s) * B)))
             return rc;
     }
     if (loss_out) {
@@ -806,10 +904,10 @@ int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t B,
     int rc;
     if ((rc = ensure_capacity(m, B))) return rc;
     HIPCHK(hipMemcpyAsync(m->d_u, ids, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, m->d_u, m->ks_u, m->iota, m->ps_u, B,
-                      side == 0 ? m->bits_u : m->bits_i, m->stream));
-    HIPCHK(hipMemcpyAsync(ks_out, m->ks_u, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(ps_out, m->ps_u, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_i, ids, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    if ((rc = sort_columns(m, m->d_u, m->d_i, B))) return rc;      // the training step's own sort path
+    HIPCHK(hipMemcpyAsync(ks_out, side == 0 ? m->ks_u : m->ks_i, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(ps_out, side == 0 ? m->ps_u : m->ps_i, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return TFR_OK;
 }

@@ -1,8 +1,12 @@
 // sort.hip - stable key sort of batch positions by row id (the integer half of the
 // deterministic segmented scatter).  Restates tf.unique + the batch-order walk of
 // unsorted_segment_sum [TF1-lib] as "stable sort by id, then walk each run in order".
-// rocPRIM's LSD radix sort is stable; only the low `end_bit` bits (enough for the table's
-// row count) are sorted.
+//
+// Two paths, both stable, both pure integer work (bit-exact against np.argsort(kind="stable")):
+//   csort  - hand-written one-pass counting sort for small tables (every row id is its own
+//            bin, all bins in LDS): 3 launches sort BOTH id columns.  This is the
+//            MovieLens-scale path, where launch count, not bytes, bounds the step.
+//   radix  - rocPRIM's LSD radix sort for big tables (only the low `end_bit` bits).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -10,6 +14,120 @@
 
 namespace tfr {
 
+// ------------------------------------------------------------------------------------
+// csort pass 1: per tile of CSORT_TILE batch entries, the rank of every entry among the
+// equal keys that precede it in the tile, and the tile's histogram.
+//   in-wave: 64 lanes find their equal-key peers with one ballot per key bit;
+//   across the 16 waves of the tile: waves take turns (in order) bumping the LDS counter of
+//   their keys, so ranks follow batch order -> the sort is stable.
+__global__ __launch_bounds__(CSORT_TILE) void k_csort_rank(CSortArgs a) {
+    extern __shared__ int32_t cnt[];
+    const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int nb = a.nbins[col];
+    for (int b = tid; b < nb; b += CSORT_TILE) cnt[b] = 0;
+    __syncthreads();
+    const int64_t k = (int64_t)tile * CSORT_TILE + tid;
+    const bool valid = k < a.B;
+    const int32_t key = valid ? (a.keys[col][k] & (nb - 1)) : 0;
+    unsigned long long mask = __ballot(valid);
+    for (int bit = 1; bit < nb; bit <<= 1) {
+        const unsigned long long m = __ballot((key & bit) != 0);
+        mask &= (key & bit) ? m : ~m;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    const int rank_in_wave = __popcll(below);
+    const int group_size = __popcll(mask);
+    int base = 0;
+    for (int w = 0; w < CSORT_TILE / 64; ++w) {
+        if (wave == w && valid) {
+            base = cnt[key];
+            if (below == 0) cnt[key] = base + group_size;     // one writer per key per wave
+        }
+        __syncthreads();
+    }
+    if (valid) a.lrank[col][k] = base + rank_in_wave;
+    for (int b = tid; b < nb; b += CSORT_TILE) a.hist[col][(size_t)tile * nb + b] = cnt[b];   // tile-major
+}
+
+// csort pass 2 (one block per column): offs[tile][bin] = number of entries with this key in
+// earlier tiles; binbase[bin] = number of entries with a smaller key.  Thread t owns bins
+// t, t+1024, ...: loads are coalesced across threads and independent along the tile loop.
+__global__ __launch_bounds__(1024) void k_csort_scan(CSortArgs a) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int col = blockIdx.y, tid = threadIdx.x;
+    const int nb = a.nbins[col], nt = a.ntiles;
+    const int32_t* __restrict__ h = a.hist[col];
+    int32_t* __restrict__ offs = a.offs[col];
+    int32_t* __restrict__ binbase = a.binbase[col];
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int b = b0 + tid;
+        int32_t run = 0;
+        if (b < nb) {
+#pragma unroll 4
+            for (int t = 0; t < nt; ++t) {
+                const int32_t v = h[(size_t)t * nb + b];
+                offs[(size_t)t * nb + b] = run;
+                run += v;
+            }
+        }
+        // exclusive scan of `run` (this bin's total) over the 1024 bins of this round
+        int32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int32_t wbase = carry_s;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        if (b < nb) binbase[b] = wbase + incl - run;
+        __syncthreads();
+        if (tid == 1023) carry_s = wbase + incl;
+        __syncthreads();
+    }
+}
+
+// csort pass 3: scatter (key, batch position) to its sorted slot.
+__global__ __launch_bounds__(CSORT_TILE) void k_csort_scatter(CSortArgs a) {
+    const int col = blockIdx.y, tile = blockIdx.x;
+    const int64_t k = (int64_t)tile * CSORT_TILE + threadIdx.x;
+    if (k >= a.B) return;
+    const int32_t key = a.keys[col][k];
+    const int nb = a.nbins[col];
+    const int32_t bin = key & (nb - 1);
+    const int32_t dst = a.binbase[col][bin] + a.offs[col][(size_t)tile * nb + bin] + a.lrank[col][k];
+    a.ks[col][dst] = key;
+    a.ps[col][dst] = (int32_t)k;
+}
+
+bool csort_eligible(int64_t B, int bits_u, int bits_i) {
+    const int bits = bits_u > bits_i ? bits_u : bits_i;
+    if (B < 1 || (1 << bits) > CSORT_MAX_BINS) return false;
+    const int64_t ntiles = (B + CSORT_TILE - 1) / CSORT_TILE;
+    return ((int64_t)1 << bits) * ntiles <= (1 << 20);       // keeps the one-block scan short
+}
+
+void launch_csort(const CSortArgs& a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csort_rank),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CSORT_MAX_BINS * 4);
+        attr_done = true;
+    }
+    const int nbmax = a.nbins[0] > a.nbins[1] ? a.nbins[0] : a.nbins[1];
+    const dim3 grid(a.ntiles, 2);
+    hipLaunchKernelGGL(k_csort_rank, grid, dim3(CSORT_TILE), (size_t)nbmax * 4, s, a);
+    hipLaunchKernelGGL(k_csort_scan, dim3(1, 2), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_csort_scatter, grid, dim3(CSORT_TILE), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------
 size_t sort_temp_bytes(int64_t n, int end_bit) {
     size_t bytes = 0;
     const unsigned int* kin = nullptr;

@@ -1,4 +1,4 @@
-// svd_kernels.h - argument blocks and launchers shared by svd_kernels.hip and api.hip.
+// svd_kernels.h - argument blocks and launchers shared by svd_kernels.hip, sort.hip and api.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,11 +8,20 @@ namespace tfr {
 enum { MODE_INFER = 0, MODE_TRAIN = 1, MODE_EVAL = 2 };
 enum { RMODE_SCRATCH = 0, RMODE_ADAM = 1, RMODE_SGD = 2 };
 
+// Runs of equal row id in the sorted order are cut into pieces of at most PIECE entries
+// (piece starts = run heads and multiples of PIECE), so no lane group ever walks more than
+// PIECE entries however skewed the ids are.
+constexpr int PIECE = 32;
+
 struct FwdArgs {
     const float* P; const float* Q; const float* bu; const float* bi; const float* mu;
     const int32_t* u; const int32_t* it; const float* r;
+    // optional fused gather from the resident store (ids != NULL): u/it/r above are then
+    // ignored and the gathered ids are written to u_out / it_out for the backward
+    const int64_t* ids; const int32_t* su; const int32_t* si; const float* sr;
+    int32_t* u_out; int32_t* it_out;
     float* logits; float* g; float* partials; int32_t* err;
-    int64_t B, U, I;
+    int64_t B, U, I, N;
     int32_t D, loss, item_abs, reg_bias;
 };
 
@@ -30,27 +39,30 @@ struct RedArgs {
     float* grad_rows; float* grad_bias; int32_t* map;
     const int32_t* err;
     int64_t B;
-    int32_t D, chunk, side, item_abs, reg_bias, frozen_rows, frozen_bias;
+    int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;
     float lam, alpha, b1, b2, eps, lr;
 };
+struct RedPair { RedArgs a[2]; };
 
 struct ApplyArgs {
     const int32_t* ks; const float* grad_rows; const float* grad_bias;
     float* w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
     const int32_t* err;
     int64_t B;
-    int32_t D, chunk, frozen_rows, frozen_bias;
+    int32_t D, frozen_rows, frozen_bias, only_split;   // only_split: runs cut into >1 piece only
     float alpha, b1, b2, eps, lr;
 };
+struct ApplyPair { ApplyArgs a[2]; };
 
 struct DenseArgs {
-    const int32_t* map; const float* grad_rows; const float* grad_bias;
+    int32_t* map; const int32_t* ks; const float* grad_rows; const float* grad_bias;
     float* w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
     const int32_t* err;
-    int64_t rows;
+    int64_t rows, B;
     int32_t D, frozen_rows, frozen_bias;
     float alpha, b1, b2, eps;
 };
+struct DensePair { DenseArgs a[2]; };
 
 struct FinArgs {
     const float* partials; int32_t nblk;
@@ -58,6 +70,19 @@ struct FinArgs {
     float* mu; float* mu_m; float* mu_v; const int32_t* err;
     int32_t update_mu, opt;
     float alpha, b1, b2, eps, lr;
+};
+
+// one-pass stable counting sort of both id columns (small tables: all bins fit in LDS)
+struct CSortArgs {
+    const int32_t* keys[2];      // [B] each
+    int32_t* ks[2]; int32_t* ps[2];
+    int32_t* lrank[2];           // [B] rank of the entry among equal keys inside its tile
+    int32_t* hist[2];            // [ntiles * nbins], tile-major: per-tile key histogram
+    int32_t* offs[2];            // [ntiles * nbins]: entries with this key in earlier tiles
+    int32_t* binbase[2];         // [nbins]: entries with a smaller key
+    int32_t nbins[2];            // power of two
+    int32_t ntiles;
+    int64_t B;
 };
 
 // row geometry for a dim: returns false if unsupported
@@ -74,15 +99,20 @@ inline bool geometry(int D, int* G, int* VEC) {
 
 int forward_grid(int64_t B, int G);
 void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s);
-void launch_seg_reduce(const RedArgs& a, int rmode, int G, int VEC, hipStream_t s);
-void launch_apply_rows(const ApplyArgs& a, int opt, int G, int VEC, hipStream_t s);
-void launch_adam_dense(const DenseArgs& a, int G, int VEC, hipStream_t s);
-void launch_clear_map(const int32_t* ks, int64_t B, int32_t* map, const int32_t* err, hipStream_t s);
+void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s);
+void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipStream_t s);
+void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s);
 void launch_gather(const GatherArgs& a, hipStream_t s);
 void launch_iota(int32_t* p, int64_t n, hipStream_t s);
 void launch_finalize(const FinArgs& a, hipStream_t s);
+void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s);
+void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s);
 
-// sort.hip (rocPRIM radix sort; integer work, stable)
+// sort.hip
+constexpr int CSORT_TILE = 1024;
+constexpr int CSORT_MAX_BINS = 16384;          // 64 KB of LDS counters
+bool csort_eligible(int64_t B, int bits_u, int bits_i);
+void launch_csort(const CSortArgs& a, hipStream_t s);
 size_t sort_temp_bytes(int64_t n, int end_bit);
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const int32_t* keys_in, int32_t* keys_out,
                       const int32_t* vals_in, int32_t* vals_out, int64_t n, int end_bit,

@@ -102,30 +102,54 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
     const float mu = *a.mu;
 
     float acc[3] = {0.f, 0.f, 0.f};    // TRAIN: loss, reg, sum g | EVAL: sse, n_equal, -
-    bool oob = false;
+    bool oob = false, oob_store = false;
 
     for (int64_t base = wave_id * SPI; base < a.B; base += nwaves * SPI) {
         int64_t k[UNR];
         int32_t u[UNR], it[UNR];
         bool ok[UNR];
+        float rr[UNR];
+        if (a.ids) {
+            // fused ShuffleIterator gather (dataio.py:115-117): id -> (user, item, rate) from the
+            // HBM-resident store; the gathered ids are kept for the backward
+            int64_t id[UNR];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                k[j] = base + j * SPW + sub;
+                ok[j] = k[j] < a.B;
+                id[j] = ok[j] ? a.ids[k[j]] : 0;
+                if ((uint64_t)id[j] >= (uint64_t)a.N) { oob_store = true; id[j] = 0; }
+            }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                u[j] = a.su[id[j]];
+                it[j] = a.si[id[j]];
+                rr[j] = a.sr[id[j]];
+                if (gl == 0 && ok[j]) { a.u_out[k[j]] = u[j]; a.it_out[k[j]] = it[j]; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                k[j] = base + j * SPW + sub;
+                ok[j] = k[j] < a.B;
+                u[j] = ok[j] ? a.u[k[j]] : 0;
+                it[j] = ok[j] ? a.it[k[j]] : 0;
+                rr[j] = (MODE != MODE_INFER && ok[j]) ? a.r[k[j]] : 0.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
-            k[j] = base + j * SPW + sub;
-            ok[j] = k[j] < a.B;
-            u[j] = ok[j] ? a.u[k[j]] : 0;
-            it[j] = ok[j] ? a.it[k[j]] : 0;
             if ((uint64_t)(int64_t)u[j] >= (uint64_t)a.U) { oob = true; u[j] = 0; }
             if ((uint64_t)(int64_t)it[j] >= (uint64_t)a.I) { oob = true; it[j] = 0; }
         }
         Frag<VEC> p[UNR], q[UNR];
-        float bsum[UNR], bu_[UNR], bi_[UNR];
+        float bu_[UNR], bi_[UNR];
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             p[j] = load_frag<VEC>(a.P + (size_t)u[j] * D, d0, D);
             q[j] = load_frag<VEC>(a.Q + (size_t)it[j] * D, d0, D);
             bu_[j] = a.bu[u[j]];
             bi_[j] = a.bi[it[j]];
-            bsum[j] = bu_[j];   // kept separate: (dot + mu) + bu + bi, ops.py:45-47 order
         }
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
@@ -137,13 +161,13 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
                 if constexpr (MODE == MODE_TRAIN) sq = fmaf(p[j].v[e], p[j].v[e], fmaf(qv, qv, sq));
             }
             s = group_sum<G>(s);
-            const float logit = ((s + mu) + bsum[j]) + bi_[j];
+            const float logit = ((s + mu) + bu_[j]) + bi_[j];      // ops.py:45-47 order
             if (gl == 0 && ok[j]) {
                 if constexpr (MODE == MODE_INFER) {
                     a.logits[k[j]] = logit;
                 } else if constexpr (MODE == MODE_TRAIN) {
                     if (a.logits) a.logits[k[j]] = logit;
-                    const float r = a.r[k[j]];
+                    const float r = rr[j];
                     float g, l;
                     if (a.loss == 0) {                 // ops.py:124  l2_loss(infer - rate)
                         g = logit - r;
@@ -157,7 +181,7 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
                     acc[2] += g;
                     if (a.reg_bias) sq = fmaf(bu_[j], bu_[j], fmaf(bi_[j], bi_[j], sq));
                 } else {
-                    const float r = a.r[k[j]];
+                    const float r = rr[j];
                     float inf = logit;                 // canonical infer = logits (README.md:33)
                     if (a.loss != 0) inf = rintf(sigmoidf_(logit));   // ops.py:77-78, half-to-even
                     const float d = inf - r;
@@ -171,12 +195,14 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
         }
     }
     if (oob) atomicOr(a.err, 1);
+    if (oob_store) atomicOr(a.err, 2);
     if constexpr (MODE != MODE_INFER) block_sum_store<3>(acc, a.partials + (size_t)blockIdx.x * 4);
 }
 
 // ------------------------------------------------------------------------------------
 // K0  triple gather from the HBM-resident (user,item,rate) store: what
 //     ShuffleIterator.next does on the host (dataio.py:115-117), ids drawn by the host.
+//     (the training path fuses this into K1; this kernel serves forward_resident)
 __global__ __launch_bounds__(256) void k_gather_triples(GatherArgs a) {
     bool oob = false;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.B;
@@ -212,163 +238,191 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 // K3  deterministic segmented reduce over a table's rows (backward of embedding_lookup:
 //     IndexedSlices -> unique + unsorted_segment_sum [TF1-lib], ops.py:143-149).
 //     Input: batch positions stably sorted by row id (ks = sorted ids, ps = positions).
-//     A lane group walks CH consecutive sorted entries and fully processes every segment
-//     that STARTS there, in batch order (fixed order -> run-to-run bit-identical, and the
-//     same order as TF-CPU's unsorted_segment_sum).
+//     A run of equal ids is cut into PIECES of <= PIECE entries (piece starts: the run head
+//     and every multiple of PIECE).  One lane group per sorted entry; groups whose entry is
+//     not a piece start exit.  A piece is summed in batch order; a run's total is its pieces
+//     added in piece order - a fixed order, so results are run-to-run bit-identical and
+//     load is balanced however skewed the ids are.
 //     per occurrence:
 //        user side: t = g_k * Qt[i_k] + lam * P[u]          Qt = |Q| if item_abs
 //        item side: t = g_k * P[u_k] * s + lam * Q[i]       s = sign(Q[i]) if item_abs
 //        bias     : t = g_k (+ lam * b[row] if reg_bias)
-//     RMODE_SCRATCH : grad row -> scratch[head position] (+ map[row] = head+1 for tf1)
-//     RMODE_ADAM    : fused lazy Adam on the row, in place
-//     RMODE_SGD     : fused var -= lr * grad, in place
+//     RMODE_SCRATCH : every piece sum -> scratch[piece start] (+ map[row] = head+1 for tf1)
+//     RMODE_ADAM/SGD: a run that is a single piece is applied in place at once (fused lazy
+//                     Adam / SGD); split runs go to scratch and k_apply_rows finishes them.
 template <int G, int VEC, int RMODE>
-__global__ __launch_bounds__(256) void k_seg_reduce(RedArgs a) {
+__global__ __launch_bounds__(256) void k_seg_reduce(RedPair pr) {
+    const RedArgs& a = pr.a[blockIdx.y];
     if (*a.err) return;                      // an out-of-range id voids the whole step
     constexpr int GPB = 256 / G;             // groups per block
     const int gl = threadIdx.x % G;
     const int d0 = gl * VEC;
     const int D = a.D;
-    const int64_t gid = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
-    const int64_t j0 = gid * a.chunk;
-    int64_t j1 = j0 + a.chunk;
-    if (j1 > a.B) j1 = a.B;
+    const int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    if (j >= a.B) return;
+    const int32_t row = a.ks[j];
+    const bool head = (j == 0) || (a.ks[j - 1] != row);
+    if (!head && (j % PIECE) != 0) return;   // not a piece start
+    int64_t bound = (j / PIECE + 1) * PIECE;
+    if (bound > a.B) bound = a.B;
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
 
-    for (int64_t j = j0; j < j1; ++j) {
-        const int32_t row = a.ks[j];
-        if (j > 0 && a.ks[j - 1] == row) continue;     // not a segment head
-        const size_t roff = (size_t)row * D;
-        const Frag<VEC> o = load_frag<VEC>(a.own + roff, d0, D);
-        const float ob = a.own_bias[row];
-        Frag<VEC> mrow, vrow;
-        float mb = 0.f, vb = 0.f;
-        if constexpr (RMODE == RMODE_ADAM) {           // issue early, used after the walk
+    const size_t roff = (size_t)row * D;
+    const Frag<VEC> o = load_frag<VEC>(a.own + roff, d0, D);
+    const float ob = a.own_bias[row];
+    Frag<VEC> mrow, vrow;
+    float mb = 0.f, vb = 0.f;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
+    if constexpr (RMODE == RMODE_ADAM) {     // issued early, used after the walk
+        if (head) {
             mrow = load_frag<VEC>(a.m + roff, d0, D);
             vrow = load_frag<VEC>(a.v + roff, d0, D);
             mb = a.bias_m[row];
             vb = a.bias_v[row];
         }
-        float sg[VEC];
+    }
+    float sg[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float x = o.v[e];
-            sg[e] = (a.side == 1 && a.item_abs) ? ((x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f)) : 1.f;
+    for (int e = 0; e < VEC; ++e) {
+        const float x = o.v[e];
+        sg[e] = (a.side == 1 && a.item_abs) ? ((x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f)) : 1.f;
+    }
+    Frag<VEC> acc;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc.v[e] = 0.f;
+    float gb = 0.f;
+    int64_t e = j;
+    int32_t nxt;
+    for (;;) {
+        const int32_t pos = a.ps[e];
+        nxt = (e + 1 < a.B) ? a.ks[e + 1] : -1;
+        const float gk = a.g[pos];
+        const int32_t pid = a.other[pos];
+        const Frag<VEC> x = load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float xv = x.v[q];
+            if (a.side == 0) { if (a.item_abs) xv = fabsf(xv); }
+            else xv = xv * sg[q];
+            acc.v[q] += gk * xv + a.lam * o.v[q];
         }
-        Frag<VEC> acc;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc.v[e] = 0.f;
-        float gb = 0.f;
-        int64_t e = j;
-        for (;;) {
-            const int32_t pos = a.ps[e];
-            const int32_t nxt = (e + 1 < a.B) ? a.ks[e + 1] : -1;
-            const float gk = a.g[pos];
-            const int32_t pid = a.other[pos];
-            const Frag<VEC> x = load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                float xv = x.v[q];
-                if (a.side == 0) { if (a.item_abs) xv = fabsf(xv); }
-                else xv = xv * sg[q];
-                acc.v[q] += gk * xv + a.lam * o.v[q];
-            }
-            gb += a.reg_bias ? (gk + a.lam * ob) : gk;
-            ++e;
-            if (nxt != row) break;
+        gb += a.reg_bias ? (gk + a.lam * ob) : gk;
+        ++e;
+        if (nxt != row || e >= bound) break;
+    }
+    const bool whole = head && (nxt != row);             // the run is this one piece
+    if (RMODE == RMODE_SCRATCH || !whole) {
+        store_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D, acc);
+        if (gl == 0) {
+            a.grad_bias[j] = gb;
+            if (head && a.map) a.map[row] = (int32_t)j + 1;
         }
-        if constexpr (RMODE == RMODE_SCRATCH) {
-            store_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D, acc);
-            if (gl == 0) {
-                a.grad_bias[j] = gb;
-                if (a.map) a.map[row] = (int32_t)j + 1;
-            }
-        } else if constexpr (RMODE == RMODE_ADAM) {
-            if (!a.frozen_rows) {
-                Frag<VEC> w = o;
+    } else if constexpr (RMODE == RMODE_ADAM) {
+        if (!a.frozen_rows) {
+            Frag<VEC> w = o;
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], acc.v[q], c);
-                store_frag<VEC>(a.own_w + roff, d0, D, w);
-                store_frag<VEC>(a.m + roff, d0, D, mrow);
-                store_frag<VEC>(a.v + roff, d0, D, vrow);
-            }
-            if (gl == 0 && !a.frozen_bias) {
-                float w = ob;
-                adam_sparse(w, mb, vb, gb, c);
-                a.bias_w[row] = w;
-                a.bias_m[row] = mb;
-                a.bias_v[row] = vb;
-            }
-        } else {
-            if (!a.frozen_rows) {
-                Frag<VEC> w = o;
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * acc.v[q];
-                store_frag<VEC>(a.own_w + roff, d0, D, w);
-            }
-            if (gl == 0 && !a.frozen_bias) a.bias_w[row] = ob - a.lr * gb;
+            for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], acc.v[q], c);
+            store_frag<VEC>(a.own_w + roff, d0, D, w);
+            store_frag<VEC>(a.m + roff, d0, D, mrow);
+            store_frag<VEC>(a.v + roff, d0, D, vrow);
         }
-        j = e - 1;                                      // skip the rest of this segment
+        if (gl == 0 && !a.frozen_bias) {
+            float w = ob;
+            adam_sparse(w, mb, vb, gb, c);
+            a.bias_w[row] = w;
+            a.bias_m[row] = mb;
+            a.bias_v[row] = vb;
+        }
+    } else if constexpr (RMODE == RMODE_SGD) {
+        if (!a.frozen_rows) {
+            Frag<VEC> w = o;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * acc.v[q];
+            store_frag<VEC>(a.own_w + roff, d0, D, w);
+        }
+        if (gl == 0 && !a.frozen_bias) a.bias_w[row] = ob - a.lr * gb;
     }
 }
 
+// a run's reduced gradient = its pieces added in piece order (head piece first)
+template <int VEC>
+__device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_rows,
+                                               const float* __restrict__ grad_bias,
+                                               const int32_t* __restrict__ ks, int64_t B, int64_t j,
+                                               int32_t row, int d0, int D, float& gb) {
+    Frag<VEC> t = load_frag<VEC>(grad_rows + (size_t)j * D, d0, D);
+    gb = grad_bias[j];
+    for (int64_t p = (j / PIECE + 1) * PIECE; p < B && ks[p] == row; p += PIECE) {
+        const Frag<VEC> x = load_frag<VEC>(grad_rows + (size_t)p * D, d0, D);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) t.v[q] += x.v[q];
+        gb += grad_bias[p];
+    }
+    return t;
+}
+
 // ------------------------------------------------------------------------------------
-// K5a  apply reduced gradients held in scratch (indexed by segment-head position) to the
-//      touched rows only: lazy Adam or SGD (ops.py:143-149).
+// K5a  apply reduced gradients held in scratch to the touched rows only: lazy Adam or SGD
+//      (ops.py:143-149).  One lane group per sorted entry; only run heads work.
+//      only_split: finish the runs k_seg_reduce could not apply in place (cut in >1 piece).
 template <int G, int VEC, int OPT>
-__global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
+__global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
+    const ApplyArgs& a = pr.a[blockIdx.y];
     if (*a.err) return;
     constexpr int GPB = 256 / G;
     const int gl = threadIdx.x % G;
     const int d0 = gl * VEC;
     const int D = a.D;
-    const int64_t gid = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
-    const int64_t j0 = gid * a.chunk;
-    int64_t j1 = j0 + a.chunk;
-    if (j1 > a.B) j1 = a.B;
+    const int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    if (j >= a.B) return;
+    const int32_t row = a.ks[j];
+    if (j > 0 && a.ks[j - 1] == row) return;             // not a run head
+    if (a.only_split) {
+        const int64_t p = (j / PIECE + 1) * PIECE;
+        if (!(p < a.B && a.ks[p] == row)) return;        // single-piece run: already applied
+    }
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
-    for (int64_t j = j0; j < j1; ++j) {
-        const int32_t row = a.ks[j];
-        if (j > 0 && a.ks[j - 1] == row) continue;
-        const size_t roff = (size_t)row * D;
-        if (!a.frozen_rows) {
-            const Frag<VEC> gr = load_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D);
-            Frag<VEC> w = load_frag<VEC>(a.w + roff, d0, D);
-            if constexpr (OPT == 0) {
-                Frag<VEC> mrow = load_frag<VEC>(a.m + roff, d0, D);
-                Frag<VEC> vrow = load_frag<VEC>(a.v + roff, d0, D);
+    const size_t roff = (size_t)row * D;
+    float gb;
+    const Frag<VEC> gr = run_total<VEC>(a.grad_rows, a.grad_bias, a.ks, a.B, j, row, d0, D, gb);
+    if (!a.frozen_rows) {
+        Frag<VEC> w = load_frag<VEC>(a.w + roff, d0, D);
+        if constexpr (OPT == 0) {
+            Frag<VEC> mrow = load_frag<VEC>(a.m + roff, d0, D);
+            Frag<VEC> vrow = load_frag<VEC>(a.v + roff, d0, D);
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], gr.v[q], c);
-                store_frag<VEC>(a.m + roff, d0, D, mrow);
-                store_frag<VEC>(a.v + roff, d0, D, vrow);
-            } else {
+            for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], gr.v[q], c);
+            store_frag<VEC>(a.m + roff, d0, D, mrow);
+            store_frag<VEC>(a.v + roff, d0, D, vrow);
+        } else {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * gr.v[q];
-            }
-            store_frag<VEC>(a.w + roff, d0, D, w);
+            for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * gr.v[q];
         }
-        if (gl == 0 && !a.frozen_bias) {
-            const float gb = a.grad_bias[j];
-            float w = a.bias_w[row];
-            if constexpr (OPT == 0) {
-                float mb = a.bias_m[row], vb = a.bias_v[row];
-                adam_sparse(w, mb, vb, gb, c);
-                a.bias_m[row] = mb;
-                a.bias_v[row] = vb;
-            } else {
-                w = w - a.lr * gb;
-            }
-            a.bias_w[row] = w;
+        store_frag<VEC>(a.w + roff, d0, D, w);
+    }
+    if (gl == 0 && !a.frozen_bias) {
+        float w = a.bias_w[row];
+        if constexpr (OPT == 0) {
+            float mb = a.bias_m[row], vb = a.bias_v[row];
+            adam_sparse(w, mb, vb, gb, c);
+            a.bias_m[row] = mb;
+            a.bias_v[row] = vb;
+        } else {
+            w = w - a.lr * gb;
         }
+        a.bias_w[row] = w;
     }
 }
 
 // ------------------------------------------------------------------------------------
 // K5b  TF1 "sparse" Adam = dense sweep: every row decays m, v and moves;
 //      touched rows (map[row] = head+1) add their reduced gradient.  One lane group per
-//      row, consecutive groups on consecutive rows -> fully coalesced streaming.
+//      row, consecutive groups on consecutive rows -> fully coalesced streaming.  The map
+//      entry is cleared by the group that consumed it.
 template <int G, int VEC>
-__global__ __launch_bounds__(256) void k_adam_dense(DenseArgs a) {
+__global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
+    const DenseArgs& a = pr.a[blockIdx.y];
     if (*a.err) return;
     constexpr int GPB = 256 / G;
     const int gl = threadIdx.x % G;
@@ -379,13 +433,16 @@ __global__ __launch_bounds__(256) void k_adam_dense(DenseArgs a) {
          row += (int64_t)gridDim.x * GPB) {
         const int32_t slot = a.map[row];
         const size_t roff = (size_t)row * D;
-        if (!a.frozen_rows) {
-            Frag<VEC> gr;
-            if (slot) gr = load_frag<VEC>(a.grad_rows + (size_t)(slot - 1) * D, d0, D);
-            else {
+        Frag<VEC> gr;
+        float gb = 0.f;
+        if (slot) {
+            gr = run_total<VEC>(a.grad_rows, a.grad_bias, a.ks, a.B, (int64_t)slot - 1, (int32_t)row, d0, D, gb);
+            if (gl == 0) a.map[row] = 0;                 // consumed (after the read above)
+        } else {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) gr.v[q] = 0.f;
-            }
+            for (int q = 0; q < VEC; ++q) gr.v[q] = 0.f;
+        }
+        if (!a.frozen_rows) {
             Frag<VEC> w = load_frag<VEC>(a.w + roff, d0, D);
             Frag<VEC> mrow = load_frag<VEC>(a.m + roff, d0, D);
             Frag<VEC> vrow = load_frag<VEC>(a.v + roff, d0, D);
@@ -396,7 +453,6 @@ __global__ __launch_bounds__(256) void k_adam_dense(DenseArgs a) {
             store_frag<VEC>(a.v + roff, d0, D, vrow);
         }
         if (gl == 0 && !a.frozen_bias) {
-            const float gb = slot ? a.grad_bias[slot - 1] : 0.f;
             float w = a.bias_w[row], mb = a.bias_m[row], vb = a.bias_v[row];
             adam_sparse(w, mb, vb, gb, c);
             a.bias_w[row] = w;
@@ -404,14 +460,6 @@ __global__ __launch_bounds__(256) void k_adam_dense(DenseArgs a) {
             a.bias_v[row] = vb;
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_clear_map(const int32_t* ks, int64_t B, int32_t* map,
-                                                    const int32_t* err) {
-    if (*err) return;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < B;
-         k += (int64_t)gridDim.x * blockDim.x)
-        map[ks[k]] = 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -452,6 +500,40 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// Variable initialisers (ops.py:8-12,29-32): truncated normal = N(0, s) resampled until
+// |x| <= 2 s [TF1-lib].  Counter-based (splitmix64 of seed and element index), so the
+// values do not depend on the launch geometry.  TF's Philox stream is not reproducible
+// here: initial values are not a parity target.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        float z = 0.f;
+        for (int attempt = 0; attempt < 16; ++attempt) {
+            const uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)k * 16 + attempt));
+            const float u1 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.f / 16777216.f);   // (0,1)
+            const float u2 = ((float)(uint32_t)((h >> 16) & 0xFFFFFF) + 0.5f) * (1.f / 16777216.f);
+            z = sqrtf(-2.f * __logf(u1)) * __cosf(6.28318530718f * u2);
+            if (fabsf(z) <= 2.f) break;
+            z = 0.f;
+        }
+        p[k] = z * stddev;
+    }
+}
+
+__global__ void k_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed) {
+    const uint64_t h = splitmix64(seed ^ 0xABCDEF12345ull);
+    const float u = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.f / 16777216.f);
+    p[0] = lo + (hi - lo) * u;
+}
+
+// ------------------------------------------------------------------------------------
 // launch helpers
 template <int MODE>
 static void launch_forward_mode(const FwdArgs& a, int G, int VEC, int grid, hipStream_t s) {
@@ -476,21 +558,22 @@ void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStr
     else launch_forward_mode<MODE_EVAL>(a, G, VEC, grid, s);
 }
 
-static int chunk_grid(int64_t B, int chunk, int G) {
-    const int64_t groups = (B + chunk - 1) / chunk;
+static int entry_grid(int64_t B, int G) {
     const int gpb = 256 / G;
-    int64_t nb = (groups + gpb - 1) / gpb;
+    int64_t nb = (B + gpb - 1) / gpb;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
 
-void launch_seg_reduce(const RedArgs& a, int rmode, int G, int VEC, hipStream_t s) {
-    const int grid = chunk_grid(a.B, a.chunk, G);
+void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s) {
+    int64_t B = p.a[0].B;
+    if (n > 1 && p.a[1].B > B) B = p.a[1].B;
+    const dim3 grid(entry_grid(B, G), n);
 #define TFR_RED_CASE(g, v)                                                                             \
     if (G == g && VEC == v) {                                                                          \
-        if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), dim3(grid), dim3(256), 0, s, a); \
-        else if (rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM>), dim3(grid), dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD>), dim3(grid), dim3(256), 0, s, a);      \
+        if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), grid, dim3(256), 0, s, p); \
+        else if (rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM>), grid, dim3(256), 0, s, p);  \
+        else hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD>), grid, dim3(256), 0, s, p);            \
         return;                                                                                        \
     }
     TFR_RED_CASE(4, 4) TFR_RED_CASE(8, 4) TFR_RED_CASE(16, 4) TFR_RED_CASE(32, 4) TFR_RED_CASE(64, 4)
@@ -498,26 +581,31 @@ void launch_seg_reduce(const RedArgs& a, int rmode, int G, int VEC, hipStream_t 
 #undef TFR_RED_CASE
 }
 
-void launch_apply_rows(const ApplyArgs& a, int opt, int G, int VEC, hipStream_t s) {
-    const int grid = chunk_grid(a.B, a.chunk, G);
-#define TFR_APP_CASE(g, v)                                                                        \
-    if (G == g && VEC == v) {                                                                     \
-        if (opt == 0) hipLaunchKernelGGL((k_apply_rows<g, v, 0>), dim3(grid), dim3(256), 0, s, a); \
-        else hipLaunchKernelGGL((k_apply_rows<g, v, 1>), dim3(grid), dim3(256), 0, s, a);         \
-        return;                                                                                   \
+void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipStream_t s) {
+    int64_t B = p.a[0].B;
+    if (n > 1 && p.a[1].B > B) B = p.a[1].B;
+    const dim3 grid(entry_grid(B, G), n);
+#define TFR_APP_CASE(g, v)                                                                  \
+    if (G == g && VEC == v) {                                                               \
+        if (opt == 0) hipLaunchKernelGGL((k_apply_rows<g, v, 0>), grid, dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((k_apply_rows<g, v, 1>), grid, dim3(256), 0, s, p);         \
+        return;                                                                             \
     }
     TFR_APP_CASE(4, 4) TFR_APP_CASE(8, 4) TFR_APP_CASE(16, 4) TFR_APP_CASE(32, 4) TFR_APP_CASE(64, 4)
     TFR_APP_CASE(4, 1) TFR_APP_CASE(8, 1) TFR_APP_CASE(16, 1) TFR_APP_CASE(32, 1) TFR_APP_CASE(64, 1)
 #undef TFR_APP_CASE
 }
 
-void launch_adam_dense(const DenseArgs& a, int G, int VEC, hipStream_t s) {
+void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s) {
     const int gpb = 256 / G;
-    int64_t nb = (a.rows + gpb - 1) / gpb;
+    int64_t rows = p.a[0].rows;
+    if (n > 1 && p.a[1].rows > rows) rows = p.a[1].rows;
+    int64_t nb = (rows + gpb - 1) / gpb;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
+    const dim3 grid((int)nb, n);
 #define TFR_DEN_CASE(g, v) \
-    if (G == g && VEC == v) { hipLaunchKernelGGL((k_adam_dense<g, v>), dim3((int)nb), dim3(256), 0, s, a); return; }
+    if (G == g && VEC == v) { hipLaunchKernelGGL((k_adam_dense<g, v>), grid, dim3(256), 0, s, p); return; }
     TFR_DEN_CASE(4, 4) TFR_DEN_CASE(8, 4) TFR_DEN_CASE(16, 4) TFR_DEN_CASE(32, 4) TFR_DEN_CASE(64, 4)
     TFR_DEN_CASE(4, 1) TFR_DEN_CASE(8, 1) TFR_DEN_CASE(16, 1) TFR_DEN_CASE(32, 1) TFR_DEN_CASE(64, 1)
 #undef TFR_DEN_CASE
@@ -530,16 +618,20 @@ static int flat_grid(int64_t n) {
     return (int)nb;
 }
 
-void launch_clear_map(const int32_t* ks, int64_t B, int32_t* map, const int32_t* err, hipStream_t s) {
-    hipLaunchKernelGGL(k_clear_map, dim3(flat_grid(B)), dim3(256), 0, s, ks, B, map, err);
-}
-
 void launch_gather(const GatherArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_triples, dim3(flat_grid(a.B)), dim3(256), 0, s, a);
 }
 
 void launch_iota(int32_t* p, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_iota, dim3(flat_grid(n)), dim3(256), 0, s, p, n);
+}
+
+void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_trunc_normal, dim3(flat_grid(n)), dim3(256), 0, s, p, n, stddev, seed);
+}
+
+void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_uniform_scalar, dim3(1), dim3(1), 0, s, p, lo, hi, seed);
 }
 
 void launch_finalize(const FinArgs& a, hipStream_t s) {

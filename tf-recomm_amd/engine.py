@@ -75,6 +75,11 @@ class SvdModel:
         L.check(self._lib.tfr_get_table(self._h, which, L.ptr_f32(out), out.size))
         return out.reshape(self._shape(which))
 
+    def init_tables(self, seed=0, feature_stddev=0.02, bias_stddev=1.0):
+        """tf.global_variables_initializer() (svd_train_val.py:53,56) with the initialisers of
+        ops.py:9-12,29-32, drawn on the device."""
+        L.check(self._lib.tfr_init_tables(self._h, int(seed), feature_stddev, bias_stddev))
+
     def set_tables(self, mu, bu, bi, P, Q):
         for which, val in ((L.MU, mu), (L.BU, bu), (L.BI, bi), (L.P, P), (L.Q, Q)):
             self.set_table(which, val)
@@ -133,6 +138,9 @@ class SvdModel:
     def upload_triples(self, users, items, rates):
         u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
         L.check(self._lib.tfr_upload_triples(self._h, L.ptr_i32(u), L.ptr_i32(i), L.ptr_f32(r), u.size))
+
+    def set_triples_dev(self, d_user, d_item, d_rate, n):
+        L.check(self._lib.tfr_set_triples_dev(self._h, d_user, d_item, d_rate, n))
 
     def train_steps_resident(self, ids, batch, want_loss=True):
         ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64)).reshape(-1)
