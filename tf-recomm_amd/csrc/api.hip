@@ -500,7 +500,8 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
 }
 
 // stable sort of batch positions by user id and by item id
-static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int64_t B) {
+static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int64_t B,
+                        const FinArgs* fin = nullptr, bool* fin_done = nullptr) {
     Prof p(m, TFR_K_SORT);
     if (m->lrank_u && csort_eligible(B, m->bits_u, m->bits_i)) {
         CSortArgs c;
@@ -511,7 +512,8 @@ static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int6
         c.nbins[0] = 1 << m->bits_u; c.nbins[1] = 1 << m->bits_i;
         c.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
         c.B = B;
-        launch_csort(c, m->stream);
+        launch_csort(c, fin, m->stream);
+        if (fin && fin_done) *fin_done = true;
         HIPCHK(hipGetLastError());
     } else {
         HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, di, m->ks_i, m->iota, m->ps_i, B, m->bits_i, m->stream));
@@ -531,11 +533,19 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
     int nblk = 0;
     hipStream_t s = m->stream;
+    bool fin_done = false;
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.partials = m->partials; f.scalars = m->scalars; f.out = out3;
+    f.mu = m->w[TFR_MU]; f.mu_m = m->m[TFR_MU]; f.mu_v = m->v[TFR_MU]; f.err = m->d_err;
+    f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
+    f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
     if (B > 0) {
         int rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk, d_store_ids);
         if (rc) return rc;
         if (d_store_ids) { du = m->d_u; di = m->d_i; }
-        if ((rc = sort_columns(m, du, di, B))) return rc;
+        f.nblk = nblk;
+        if ((rc = sort_columns(m, du, di, B, &f, &fin_done))) return rc;
         RedArgs r;
         memset(&r, 0, sizeof(r));
         r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
@@ -627,13 +637,8 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         launch_adam_dense(dp, 2, m->G, m->VEC, s);
         HIPCHK(hipGetLastError());
     }
-    FinArgs f;
-    memset(&f, 0, sizeof(f));
-    f.partials = m->partials; f.nblk = nblk; f.scalars = m->scalars; f.out = out3;
-    f.mu = m->w[TFR_MU]; f.mu_m = m->m[TFR_MU]; f.mu_v = m->v[TFR_MU]; f.err = m->d_err;
-    f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
-    f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
-    {
+    if (!fin_done) {
+        f.nblk = nblk;
         Prof p(m, TFR_K_FINALIZE);
         launch_finalize(f, s);
     }

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "svd_kernels.h"
+#include "finalize.inc.h"
 
 namespace tfr {
 
@@ -52,8 +53,28 @@ __global__ __launch_bounds__(CSORT_TILE) void k_csort_rank(CSortArgs a) {
 
 // csort pass 2 (one block per column): offs[tile][bin] = number of entries with this key in
 // earlier tiles; binbase[bin] = number of entries with a smaller key.  Thread t owns bins
-// t, t+1024, ...: loads are coalesced across threads and independent along the tile loop.
-__global__ __launch_bounds__(1024) void k_csort_scan(CSortArgs a) {
+// t, t+1024, ...: loads are coalesced across threads and all issued before the first use.
+// blockIdx.y == 2 (optional) runs the step's finalize (K4) instead, saving a launch.
+struct ScanFinArgs { CSortArgs c; FinArgs f; };
+
+template <int NT>
+__device__ __forceinline__ int32_t tile_prefix(const int32_t* __restrict__ h, int32_t* __restrict__ offs,
+                                               int nb, int nt, int b) {
+    int32_t v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] = (t < nt) ? h[(size_t)t * nb + b] : 0;
+    int32_t run = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < nt) offs[(size_t)t * nb + b] = run;
+        run += v[t];
+    }
+    return run;
+}
+
+__global__ __launch_bounds__(1024) void k_csort_scan(ScanFinArgs sa) {
+    if (blockIdx.y == 2) { finalize_body(sa.f); return; }
+    const CSortArgs& a = sa.c;
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
     const int col = blockIdx.y, tid = threadIdx.x;
@@ -68,11 +89,13 @@ __global__ __launch_bounds__(1024) void k_csort_scan(CSortArgs a) {
         const int b = b0 + tid;
         int32_t run = 0;
         if (b < nb) {
-#pragma unroll 4
-            for (int t = 0; t < nt; ++t) {
-                const int32_t v = h[(size_t)t * nb + b];
-                offs[(size_t)t * nb + b] = run;
-                run += v;
+            if (nt <= 16) run = tile_prefix<16>(h, offs, nb, nt, b);
+            else {
+                for (int t = 0; t < nt; ++t) {
+                    const int32_t v = h[(size_t)t * nb + b];
+                    offs[(size_t)t * nb + b] = run;
+                    run += v;
+                }
             }
         }
         // exclusive scan of `run` (this bin's total) over the 1024 bins of this round
@@ -113,7 +136,7 @@ bool csort_eligible(int64_t B, int bits_u, int bits_i) {
     return ((int64_t)1 << bits) * ntiles <= (1 << 20);       // keeps the one-block scan short
 }
 
-void launch_csort(const CSortArgs& a, hipStream_t s) {
+void launch_csort(const CSortArgs& a, const FinArgs* fin, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_csort_rank),
@@ -123,7 +146,10 @@ void launch_csort(const CSortArgs& a, hipStream_t s) {
     const int nbmax = a.nbins[0] > a.nbins[1] ? a.nbins[0] : a.nbins[1];
     const dim3 grid(a.ntiles, 2);
     hipLaunchKernelGGL(k_csort_rank, grid, dim3(CSORT_TILE), (size_t)nbmax * 4, s, a);
-    hipLaunchKernelGGL(k_csort_scan, dim3(1, 2), dim3(1024), 0, s, a);
+    ScanFinArgs sa;
+    sa.c = a;
+    if (fin) sa.f = *fin; else memset(&sa.f, 0, sizeof(sa.f));
+    hipLaunchKernelGGL(k_csort_scan, dim3(1, fin ? 3 : 2), dim3(1024), 0, s, sa);
     hipLaunchKernelGGL(k_csort_scatter, grid, dim3(CSORT_TILE), 0, s, a);
 }
 

@@ -8,10 +8,9 @@ namespace tfr {
 enum { MODE_INFER = 0, MODE_TRAIN = 1, MODE_EVAL = 2 };
 enum { RMODE_SCRATCH = 0, RMODE_ADAM = 1, RMODE_SGD = 2 };
 
-// Runs of equal row id in the sorted order are cut into pieces of at most PIECE entries
-// (piece starts = run heads and multiples of PIECE), so no lane group ever walks more than
-// PIECE entries however skewed the ids are.
-constexpr int PIECE = 32;
+// Runs of equal row id in the sorted order are cut into pieces: piece starts = run heads and
+// multiples of PIECE = 1024/G (the span of one k_seg_reduce block), so the work per block is
+// fixed however skewed the ids are.
 
 struct FwdArgs {
     const float* P; const float* Q; const float* bu; const float* bi; const float* mu;
@@ -112,7 +111,7 @@ void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hip
 constexpr int CSORT_TILE = 1024;
 constexpr int CSORT_MAX_BINS = 16384;          // 64 KB of LDS counters
 bool csort_eligible(int64_t B, int bits_u, int bits_i);
-void launch_csort(const CSortArgs& a, hipStream_t s);
+void launch_csort(const CSortArgs& a, const FinArgs* fin, hipStream_t s);   // fin: run K4 in the scan launch
 size_t sort_temp_bytes(int64_t n, int end_bit);
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const int32_t* keys_in, int32_t* keys_out,
                       const int32_t* vals_in, int32_t* vals_out, int64_t n, int end_bit,

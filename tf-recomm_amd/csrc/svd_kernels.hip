@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svd_kernels.h"
+#include "finalize.inc.h"
 
 namespace tfr {
 
@@ -238,80 +239,93 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 // K3  deterministic segmented reduce over a table's rows (backward of embedding_lookup:
 //     IndexedSlices -> unique + unsorted_segment_sum [TF1-lib], ops.py:143-149).
 //     Input: batch positions stably sorted by row id (ks = sorted ids, ps = positions).
-//     A run of equal ids is cut into PIECES of <= PIECE entries (piece starts: the run head
-//     and every multiple of PIECE).  One lane group per sorted entry; groups whose entry is
-//     not a piece start exit.  A piece is summed in batch order; a run's total is its pieces
-//     added in piece order - a fixed order, so results are run-to-run bit-identical and
-//     load is balanced however skewed the ids are.
-//     per occurrence:
-//        user side: t = g_k * Qt[i_k] + lam * P[u]          Qt = |Q| if item_abs
-//        item side: t = g_k * P[u_k] * s + lam * Q[i]       s = sign(Q[i]) if item_abs
-//        bias     : t = g_k (+ lam * b[row] if reg_bias)
+//     One 1024-thread block owns EPB = 1024/G consecutive sorted entries (a PIECE), one
+//     lane group per entry:
+//       phase 1 (all groups in parallel, no walk): the entry's contribution
+//          user side: t = g_k * Qt[i_k] + lam * P[u]          Qt = |Q| if item_abs
+//          item side: t = g_k * P[u_k] * s + lam * Q[i]       s = sign(Q[i]) if item_abs
+//          bias     : t = g_k (+ lam * b[row] if reg_bias)          
+//        goes to LDS;
+//       phase 2: the group at each piece start (run head, or first entry of the block) adds
+//        its run's contributions from LDS in entry order = batch order.
+//     A run's total is its pieces added in piece order: a fixed order, so results are
+//     run-to-run bit-identical, and the work is balanced however skewed the ids are.
 //     RMODE_SCRATCH : every piece sum -> scratch[piece start] (+ map[row] = head+1 for tf1)
-//     RMODE_ADAM/SGD: a run that is a single piece is applied in place at once (fused lazy
+//     RMODE_ADAM/SGD: a run that lies inside one block is applied in place at once (fused lazy
 //                     Adam / SGD); split runs go to scratch and k_apply_rows finishes them.
 template <int G, int VEC, int RMODE>
-__global__ __launch_bounds__(256) void k_seg_reduce(RedPair pr) {
+__global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
+    constexpr int EPB = 1024 / G;
+    __shared__ float lds_t[EPB * G * VEC];
+    __shared__ float lds_gb[EPB];
+    __shared__ int32_t lds_key[EPB];
     const RedArgs& a = pr.a[blockIdx.y];
-    if (*a.err) return;                      // an out-of-range id voids the whole step
-    constexpr int GPB = 256 / G;             // groups per block
+    const int32_t err = *a.err;
+    const int grp = threadIdx.x / G;
     const int gl = threadIdx.x % G;
     const int d0 = gl * VEC;
     const int D = a.D;
-    const int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
-    if (j >= a.B) return;
-    const int32_t row = a.ks[j];
-    const bool head = (j == 0) || (a.ks[j - 1] != row);
-    if (!head && (j % PIECE) != 0) return;   // not a piece start
-    int64_t bound = (j / PIECE + 1) * PIECE;
-    if (bound > a.B) bound = a.B;
+    const int64_t blk0 = (int64_t)blockIdx.x * EPB;
+    const int64_t j = blk0 + grp;
+    const bool valid = j < a.B;
+    int32_t row = -1, prev = -2, pos = 0;
+    if (valid) {
+        row = a.ks[j];
+        prev = (j > 0) ? a.ks[j - 1] : -2;
+        pos = a.ps[j];
+    }
+    if (err || blk0 >= a.B) return;          // an out-of-range id voids the whole step (block-uniform)
+    const bool head = valid && (prev != row);
+    const bool pstart = valid && (head || grp == 0);
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
+    const size_t roff = (size_t)(valid ? row : 0) * D;
 
-    const size_t roff = (size_t)row * D;
-    const Frag<VEC> o = load_frag<VEC>(a.own + roff, d0, D);
-    const float ob = a.own_bias[row];
-    Frag<VEC> mrow, vrow;
-    float mb = 0.f, vb = 0.f;
+    Frag<VEC> o, t, mrow, vrow;
+    float ob = 0.f, tb = 0.f, mb = 0.f, vb = 0.f;
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) { mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
-    if constexpr (RMODE == RMODE_ADAM) {     // issued early, used after the walk
-        if (head) {
-            mrow = load_frag<VEC>(a.m + roff, d0, D);
-            vrow = load_frag<VEC>(a.v + roff, d0, D);
-            mb = a.bias_m[row];
-            vb = a.bias_v[row];
-        }
-    }
-    float sg[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const float x = o.v[e];
-        sg[e] = (a.side == 1 && a.item_abs) ? ((x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f)) : 1.f;
-    }
-    Frag<VEC> acc;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc.v[e] = 0.f;
-    float gb = 0.f;
-    int64_t e = j;
-    int32_t nxt;
-    for (;;) {
-        const int32_t pos = a.ps[e];
-        nxt = (e + 1 < a.B) ? a.ks[e + 1] : -1;
+    for (int q = 0; q < VEC; ++q) { o.v[q] = 0.f; t.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
+    if (valid) {
         const float gk = a.g[pos];
         const int32_t pid = a.other[pos];
         const Frag<VEC> x = load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
+        o = load_frag<VEC>(a.own + roff, d0, D);
+        ob = a.own_bias[row];
+        if constexpr (RMODE == RMODE_ADAM) {
+            if (head) {
+                mrow = load_frag<VEC>(a.m + roff, d0, D);
+                vrow = load_frag<VEC>(a.v + roff, d0, D);
+                mb = a.bias_m[row];
+                vb = a.bias_v[row];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             float xv = x.v[q];
             if (a.side == 0) { if (a.item_abs) xv = fabsf(xv); }
-            else xv = xv * sg[q];
-            acc.v[q] += gk * xv + a.lam * o.v[q];
+            else if (a.item_abs) xv = xv * ((o.v[q] > 0.f) ? 1.f : ((o.v[q] < 0.f) ? -1.f : 0.f));
+            t.v[q] = gk * xv + a.lam * o.v[q];
         }
-        gb += a.reg_bias ? (gk + a.lam * ob) : gk;
-        ++e;
-        if (nxt != row || e >= bound) break;
+        tb = a.reg_bias ? (gk + a.lam * ob) : gk;
     }
-    const bool whole = head && (nxt != row);             // the run is this one piece
+    // contributions to LDS ([entry][G*VEC], a lane's VEC floats contiguous)
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) lds_t[(grp * G + gl) * VEC + q] = t.v[q];
+    if (gl == 0) { lds_gb[grp] = tb; lds_key[grp] = row; }
+    __syncthreads();
+    if (!pstart) return;
+
+    Frag<VEC> acc = t;
+    float gb = tb;
+    int e = grp + 1;
+    while (e < EPB && lds_key[e] == row) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc.v[q] += lds_t[(e * G + gl) * VEC + q];
+        gb += lds_gb[e];
+        ++e;
+    }
+    bool cont = false;                                   // does the run continue in the next block?
+    if (e == EPB && blk0 + EPB < a.B) cont = (a.ks[blk0 + EPB] == row);
+    const bool whole = head && !cont;
     if (RMODE == RMODE_SCRATCH || !whole) {
         store_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D, acc);
         if (gl == 0) {
@@ -345,8 +359,9 @@ __global__ __launch_bounds__(256) void k_seg_reduce(RedPair pr) {
     }
 }
 
-// a run's reduced gradient = its pieces added in piece order (head piece first)
-template <int VEC>
+// a run's reduced gradient = its pieces added in piece order (head piece first); pieces
+// start at the run head and at every multiple of PIECE (= the reduce kernel's block span)
+template <int VEC, int PIECE>
 __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_rows,
                                                const float* __restrict__ grad_bias,
                                                const int32_t* __restrict__ ks, int64_t B, int64_t j,
@@ -368,8 +383,9 @@ __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_ro
 //      only_split: finish the runs k_seg_reduce could not apply in place (cut in >1 piece).
 template <int G, int VEC, int OPT>
 __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
+    constexpr int PIECE = 1024 / G;
     const ApplyArgs& a = pr.a[blockIdx.y];
-    if (*a.err) return;
+    const int32_t err = *a.err;
     constexpr int GPB = 256 / G;
     const int gl = threadIdx.x % G;
     const int d0 = gl * VEC;
@@ -377,20 +393,28 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
     const int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
     if (j >= a.B) return;
     const int32_t row = a.ks[j];
-    if (j > 0 && a.ks[j - 1] == row) return;             // not a run head
+    const int32_t prev = (j > 0) ? a.ks[j - 1] : -2;
+    if (err || prev == row) return;                      // voided step / not a run head
     if (a.only_split) {
         const int64_t p = (j / PIECE + 1) * PIECE;
         if (!(p < a.B && a.ks[p] == row)) return;        // single-piece run: already applied
     }
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
     const size_t roff = (size_t)row * D;
-    float gb;
-    const Frag<VEC> gr = run_total<VEC>(a.grad_rows, a.grad_bias, a.ks, a.B, j, row, d0, D, gb);
-    if (!a.frozen_rows) {
-        Frag<VEC> w = load_frag<VEC>(a.w + roff, d0, D);
+    Frag<VEC> w, mrow, vrow;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
+    if (!a.frozen_rows) {                                // issued before the piece walk
+        w = load_frag<VEC>(a.w + roff, d0, D);
         if constexpr (OPT == 0) {
-            Frag<VEC> mrow = load_frag<VEC>(a.m + roff, d0, D);
-            Frag<VEC> vrow = load_frag<VEC>(a.v + roff, d0, D);
+            mrow = load_frag<VEC>(a.m + roff, d0, D);
+            vrow = load_frag<VEC>(a.v + roff, d0, D);
+        }
+    }
+    float gb;
+    const Frag<VEC> gr = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, a.B, j, row, d0, D, gb);
+    if (!a.frozen_rows) {
+        if constexpr (OPT == 0) {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], gr.v[q], c);
             store_frag<VEC>(a.m + roff, d0, D, mrow);
@@ -402,16 +426,16 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
         store_frag<VEC>(a.w + roff, d0, D, w);
     }
     if (gl == 0 && !a.frozen_bias) {
-        float w = a.bias_w[row];
+        float bw = a.bias_w[row];
         if constexpr (OPT == 0) {
             float mb = a.bias_m[row], vb = a.bias_v[row];
-            adam_sparse(w, mb, vb, gb, c);
+            adam_sparse(bw, mb, vb, gb, c);
             a.bias_m[row] = mb;
             a.bias_v[row] = vb;
         } else {
-            w = w - a.lr * gb;
+            bw = bw - a.lr * gb;
         }
-        a.bias_w[row] = w;
+        a.bias_w[row] = bw;
     }
 }
 
@@ -422,6 +446,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
 //      entry is cleared by the group that consumed it.
 template <int G, int VEC>
 __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
+    constexpr int PIECE = 1024 / G;
     const DenseArgs& a = pr.a[blockIdx.y];
     if (*a.err) return;
     constexpr int GPB = 256 / G;
@@ -433,19 +458,26 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
          row += (int64_t)gridDim.x * GPB) {
         const int32_t slot = a.map[row];
         const size_t roff = (size_t)row * D;
+        Frag<VEC> w, mrow, vrow;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
+        if (!a.frozen_rows) {                            // independent of the map: issue first
+            w = load_frag<VEC>(a.w + roff, d0, D);
+            mrow = load_frag<VEC>(a.m + roff, d0, D);
+            vrow = load_frag<VEC>(a.v + roff, d0, D);
+        }
+        float bw = 0.f, mb = 0.f, vb = 0.f;
+        if (gl == 0 && !a.frozen_bias) { bw = a.bias_w[row]; mb = a.bias_m[row]; vb = a.bias_v[row]; }
         Frag<VEC> gr;
         float gb = 0.f;
         if (slot) {
-            gr = run_total<VEC>(a.grad_rows, a.grad_bias, a.ks, a.B, (int64_t)slot - 1, (int32_t)row, d0, D, gb);
+            gr = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, a.B, (int64_t)slot - 1, (int32_t)row, d0, D, gb);
             if (gl == 0) a.map[row] = 0;                 // consumed (after the read above)
         } else {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) gr.v[q] = 0.f;
         }
         if (!a.frozen_rows) {
-            Frag<VEC> w = load_frag<VEC>(a.w + roff, d0, D);
-            Frag<VEC> mrow = load_frag<VEC>(a.m + roff, d0, D);
-            Frag<VEC> vrow = load_frag<VEC>(a.v + roff, d0, D);
 #pragma unroll
             for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], gr.v[q], c);
             store_frag<VEC>(a.w + roff, d0, D, w);
@@ -453,9 +485,8 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
             store_frag<VEC>(a.v + roff, d0, D, vrow);
         }
         if (gl == 0 && !a.frozen_bias) {
-            float w = a.bias_w[row], mb = a.bias_m[row], vb = a.bias_v[row];
-            adam_sparse(w, mb, vb, gb, c);
-            a.bias_w[row] = w;
+            adam_sparse(bw, mb, vb, gb, c);
+            a.bias_w[row] = bw;
             a.bias_m[row] = mb;
             a.bias_v[row] = vb;
         }
@@ -463,41 +494,8 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
 }
 
 // ------------------------------------------------------------------------------------
-// K4  finalize: fixed-order reduction of the forward's per-block partials -> {data loss,
-//     regulariser, sum g}; dense update of bias_global (ApplyAdam dense kernel [TF1-lib]:
-//     m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= alpha*m/(sqrt(v)+eps); or var -= lr*g).
-__global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int b = threadIdx.x; b < a.nblk; b += 256) {
-        acc[0] += a.partials[(size_t)b * 4 + 0];
-        acc[1] += a.partials[(size_t)b * 4 + 1];
-        acc[2] += a.partials[(size_t)b * 4 + 2];
-    }
-    __shared__ float tot[3];
-    block_sum_store<3>(acc, tot);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a.scalars[0] = tot[0];
-        a.scalars[1] = tot[1];
-        a.scalars[2] = tot[2];
-        if (a.out) { a.out[0] = tot[0]; a.out[1] = tot[1]; a.out[2] = tot[2]; }
-        if (a.update_mu && *a.err == 0) {
-            const float g = tot[2];
-            float w = *a.mu;
-            if (a.opt == 0) {
-                float m = *a.mu_m, v = *a.mu_v;
-                m += (g - m) * (1.f - a.b1);
-                v += (g * g - v) * (1.f - a.b2);
-                w -= (a.alpha * m) / (sqrtf(v) + a.eps);
-                *a.mu_m = m;
-                *a.mu_v = v;
-            } else {
-                w -= a.lr * g;
-            }
-            *a.mu = w;
-        }
-    }
-}
+// K4  finalize (body in finalize.inc.h; the small-table path runs it inside the csort scan launch)
+__global__ __launch_bounds__(256) void k_finalize(FinArgs a) { finalize_body(a); }
 
 // ------------------------------------------------------------------------------------
 // Variable initialisers (ops.py:8-12,29-32): truncated normal = N(0, s) resampled until
@@ -568,12 +566,15 @@ static int entry_grid(int64_t B, int G) {
 void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s) {
     int64_t B = p.a[0].B;
     if (n > 1 && p.a[1].B > B) B = p.a[1].B;
-    const dim3 grid(entry_grid(B, G), n);
+    const int epb = 1024 / G;
+    int64_t nb = (B + epb - 1) / epb;
+    if (nb < 1) nb = 1;
+    const dim3 grid((int)nb, n);
 #define TFR_RED_CASE(g, v)                                                                             \
     if (G == g && VEC == v) {                                                                          \
-        if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), grid, dim3(256), 0, s, p); \
-        else if (rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM>), grid, dim3(256), 0, s, p);  \
-        else hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD>), grid, dim3(256), 0, s, p);            \
+        if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), grid, dim3(1024), 0, s, p); \
+        else if (rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM>), grid, dim3(1024), 0, s, p);  \
+        else hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD>), grid, dim3(1024), 0, s, p);           \
         return;                                                                                        \
     }
     TFR_RED_CASE(4, 4) TFR_RED_CASE(8, 4) TFR_RED_CASE(16, 4) TFR_RED_CASE(32, 4) TFR_RED_CASE(64, 4)
