@@ -1,0 +1,146 @@
+"""The reference-shaped surface on the GPU: Session.run over ops.inference_svd /
+ops.optimization, the svd() driver loop and Saver (svd_train_val.py:40-72,106-198)."""
+import numpy as np
+import pytest
+
+from tfrecomm_amd import _lib as L
+from tfrecomm_amd import dataio, graph as tf, ops, svd_train_val
+from oracle import svd_oracle as so
+from tests.util import RTOL, assert_close, make_oracle, rand_tables
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def fresh_graph():
+    tf.reset_default_graph()
+    yield
+    tf.reset_default_graph()
+
+
+def test_session_run_matches_oracle_canonical():
+    U, I, D, B = 120, 90, 15, 256
+    rs = np.random.RandomState(0)
+    t = rand_tables(rs, U, I, D)
+    user_batch = tf.placeholder("int32", shape=[None], name="id_user")
+    item_batch = tf.placeholder("int32", shape=[None], name="id_item")
+    rate_batch = tf.placeholder("float32", shape=[None])
+    infer, regularizer = ops.inference_svd(user_batch, item_batch, user_num=U, item_num=I, dim=D)
+    global_step = tf.get_or_create_global_step()
+    cost, train_op = ops.optimization(infer, regularizer, rate_batch, learning_rate=1e-3, reg=0.05)
+    logits = tf.get_default_graph().node("logits", "logits")
+    orc = make_oracle(U, I, D, t, optimizer="adam", adam_mode="tf1", lr=1e-3, reg=0.05)
+    with tf.Session() as sess:
+        sess.run(tf.group(tf.global_variables_initializer(), tf.local_variables_initializer()))
+        sess.model.set_tables(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])       # inject: init is not a parity target
+        it = dataio.ShuffleIterator([rs.randint(0, U, 5000).astype(np.int32), rs.randint(0, I, 5000).astype(np.int32),
+                                     rs.randint(1, 6, 5000).astype(np.float32)], batch_size=B)
+        np.random.seed(13575)
+        for s in range(3):
+            users, items, rates = next(it)                                    # float64 columns
+            _, lg, inf, c, rg = sess.run([train_op, logits, infer, cost, regularizer],
+                                         feed_dict={user_batch: users, item_batch: items, rate_batch: rates})
+            wl, wloss, wreg = orc.train_step(users, items, rates)
+            assert_close(lg, wl, rtol=RTOL * (s + 1))
+            assert np.array_equal(inf, lg)                                    # canonical infer = logits
+            assert_close(c, wloss, rtol=RTOL * (s + 1))
+            assert_close(rg, wreg, rtol=RTOL * (s + 1))
+        assert sess.run(global_step) == 3
+        vu, vi = rs.randint(0, U, 777), rs.randint(0, I, 777)
+        lg, inf = sess.run([logits, infer], feed_dict={user_batch: vu, item_batch: vi})
+        assert_close(lg, orc.forward(vu, vi), rtol=4 * RTOL)
+        P = sess.run(ops.variables()["user_features"])
+        assert P.shape == (U, D)
+        assert_close(P, orc.P, rtol=4 * RTOL)
+        with pytest.raises(IndexError):
+            sess.run(logits, feed_dict={user_batch: np.array([U]), item_batch: np.array([0])})
+
+
+def test_session_fork_style_nll():
+    U, I, D, B = 60, 50, 20, 128
+    rs = np.random.RandomState(1)
+    t = rand_tables(rs, U, I, D)
+    ub, ib, rb = tf.placeholder("int32"), tf.placeholder("int32"), tf.placeholder("float32")
+    wb, fb = tf.placeholder("float32", name="nb_wins"), tf.placeholder("float32", name="nb_fails")
+    infer, logits, regularizer, user_bias, user_features, item_bias, item_features = ops.inference_svd(
+        ub, ib, wb, fb, user_num=U, item_num=I, dim=D, device="/cpu:0", fork_semantics=True)
+    tf.get_or_create_global_step()
+    cost_nll, train_op = ops.optimization(infer, logits, regularizer, rb, learning_rate=5e-3, reg=0.01, device="/cpu:0")
+    orc = make_oracle(U, I, D, t, loss="nll", item_abs=True, reg_bias=True, optimizer="sgd", lr=5e-3, reg=0.01)
+    with tf.Session() as sess:
+        sess.run(tf.global_variables_initializer())
+        sess.model.set_tables(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        u, i = rs.randint(0, U, B), rs.randint(0, I, B)
+        r = (rs.rand(B) < 0.5).astype(np.float32)
+        _, lg, inf = sess.run([train_op, logits, infer], feed_dict={ub: u, ib: i, rb: r, wb: r, fb: r})
+        wl, wloss, _ = orc.train_step(u, i, r)
+        assert_close(lg, wl)
+        assert np.array_equal(inf, so.head(lg.astype(np.float64), "nll"))
+        nll = sess.run(cost_nll, feed_dict={rb: r, logits: lg})               # svd_train_val.py:94
+        assert_close(nll, wloss, rtol=1e-5)
+        assert_close(sess.run(user_features), orc.P, rtol=2 * RTOL)
+
+
+def test_svd_driver_prints_reference_rows_and_learns(tmp_path):
+    U, I = 300, 200
+    train, val = svd_train_val.synthetic_frames(U, I, 40000, seed=5)
+    np.random.seed(13575)
+    lines = []
+    rows = svd_train_val.svd(train, val, user_num=U, item_num=I, dim=15, batch_size=1000, epoch_max=6,
+                             learning_rate=5e-3, reg=0.02, save_path=str(tmp_path / "fm.ckpt"), log=lines.append)
+    assert lines[0] == "epoch train_error val_error elapsed_time"            # README.md:49
+    assert len(rows) == 6 and [r[0] for r in rows] == list(range(6))
+    assert lines[1].endswith("(s)") and len(lines[1].split()) == 4
+    assert rows[0][2] > 2.0                                                   # epoch 0 = after ONE step (README.md:50)
+    assert rows[-1][2] < rows[1][2] < rows[0][2]                              # validation error falls
+    assert rows[-1][2] < 1.2
+    ck = np.load(str(tmp_path / "fm.ckpt.npz"))
+    assert ck["user_features"].shape == (U, 15) and int(ck["global_step"]) == 6 * 36
+    assert "user_features/Adam" in ck.files and "bias_global" in ck.files
+
+
+def test_saver_roundtrip_resumes_bit_identically(tmp_path):
+    U, I, D, B = 80, 60, 8, 200
+    rs = np.random.RandomState(2)
+    batches = [(rs.randint(0, U, B), rs.randint(0, I, B), rs.randint(1, 6, B).astype(np.float32)) for _ in range(4)]
+
+    def build():
+        tf.reset_default_graph()
+        ub, ib, rb = tf.placeholder("int32"), tf.placeholder("int32"), tf.placeholder("float32")
+        infer, reg = ops.inference_svd(ub, ib, U, I, D)
+        tf.get_or_create_global_step()
+        _, train_op = ops.optimization(infer, reg, rb, learning_rate=1e-2, reg=0.05)
+        return ub, ib, rb, train_op
+    ub, ib, rb, train_op = build()
+    with tf.Session(seed=3) as sess:
+        sess.run(tf.global_variables_initializer())
+        for b in batches[:2]:
+            sess.run(train_op, feed_dict={ub: b[0], ib: b[1], rb: b[2]})
+        tf.Saver().save(sess, str(tmp_path / "ck"))
+        for b in batches[2:]:
+            sess.run(train_op, feed_dict={ub: b[0], ib: b[1], rb: b[2]})
+        want = sess.model.tables()
+    ub, ib, rb, train_op = build()
+    with tf.Session(seed=99) as sess:
+        tf.Saver().restore(sess, str(tmp_path / "ck"))
+        assert sess.model.step == 2
+        for b in batches[2:]:
+            sess.run(train_op, feed_dict={ub: b[0], ib: b[1], rb: b[2]})
+        got = sess.model.tables()
+    for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+        assert np.array_equal(got[tid], want[tid])
+
+
+def test_device_initialisers_have_the_reference_distributions():
+    """ops.py:9-12,29-32: truncated normal sd 1 (biases) / sd 0.02 (features), |x| <= 2 sd."""
+    import tfrecomm_amd as T
+    with T.SvdModel(20000, 3000, 16) as m:
+        m.init_tables(seed=1)
+        t = m.tables()
+    for tid, sd in ((L.P, 0.02), (L.Q, 0.02), (L.BU, 1.0), (L.BI, 1.0)):
+        x = t[tid].reshape(-1).astype(np.float64)
+        assert np.abs(x).max() <= 2 * sd * (1 + 1e-6)
+        assert abs(x.mean()) < 0.05 * sd
+        assert abs(x.std() / sd - 0.8796) < 0.02            # std of a normal truncated at 2 sigma
+    assert abs(float(t[L.MU])) <= np.sqrt(3) + 1e-6
+    assert not np.array_equal(t[L.P][:100], t[L.Q][:100])

@@ -1,0 +1,73 @@
+"""Graph-recording host code (ops / graph) - call shapes of ops.py:6,118 and
+svd_train_val.py:40-57.  CPU only: nothing here creates a device model."""
+import numpy as np
+import pytest
+
+from tfrecomm_amd import _lib as L
+from tfrecomm_amd import graph as tf
+from tfrecomm_amd import ops
+
+
+@pytest.fixture(autouse=True)
+def fresh_graph():
+    tf.reset_default_graph()
+    yield
+    tf.reset_default_graph()
+
+
+def _ph():
+    return tf.placeholder("int32", shape=[None], name="id_user"), tf.placeholder("int32", shape=[None], name="id_item"), \
+        tf.placeholder("float32", shape=[None])
+
+
+def test_north_star_signature():
+    u, i, r = _ph()
+    infer, reg = ops.inference_svd(u, i, 6040, 3952, 15)               # (user_batch,item_batch,user_num,item_num,dim)
+    spec = tf.get_default_graph().spec
+    assert (spec["user_num"], spec["item_num"], spec["dim"]) == (6040, 3952, 15)
+    assert (spec["loss"], spec["item_abs"], spec["reg_bias"]) == ("mse", False, False)
+    with pytest.raises(AssertionError):                                # ops.py:119-120: needs a global step
+        ops.optimization(infer, reg, r, learning_rate=1e-3, reg=0.05)
+    tf.get_or_create_global_step()
+    cost, train_op = ops.optimization(infer, reg, r, learning_rate=1e-3, reg=0.05)
+    assert tf.get_default_graph().train == dict(optimizer="adam", adam_mode="tf1", lr=1e-3, reg=0.05, frozen=0)
+    assert cost.kind == "cost" and train_op.kind == "train_op"
+
+
+def test_fork_signature_and_var_list():
+    u, i, r = _ph()
+    w, f = tf.placeholder("float32", name="nb_wins"), tf.placeholder("float32", name="nb_fails")
+    out = ops.inference_svd(u, i, w, f, user_num=30, item_num=20, dim=20, device="/cpu:0", fork_semantics=True)
+    assert len(out) == 7                                               # ops.py:91
+    infer, logits, regularizer, user_bias, user_features, item_bias, item_features = out
+    spec = tf.get_default_graph().spec
+    assert (spec["loss"], spec["item_abs"], spec["reg_bias"]) == ("nll", True, True)
+    tf.get_or_create_global_step()
+    ops.optimization(infer, logits, regularizer, r, learning_rate=5e-3, reg=0.01, device="/cpu:0",
+                     var_list=[user_bias, user_features])               # adaptive_test.py:28
+    t = tf.get_default_graph().train
+    assert t["optimizer"] == "sgd"                                     # ops.py:145,149
+    assert t["frozen"] == (1 << L.MU) | (1 << L.BI) | (1 << L.Q)
+
+
+def test_default_is_dim_5_and_bad_arguments():
+    u, i, r = _ph()
+    ops.inference_svd(u, i, user_num=10, item_num=10)
+    assert tf.get_default_graph().spec["dim"] == 5                     # ops.py:6 default
+    with pytest.raises(RuntimeError):
+        ops.inference_svd(u, i, user_num=10, item_num=10)              # one model per graph
+    tf.reset_default_graph()
+    with pytest.raises(TypeError):
+        ops.inference_svd(u, i, 10, 10, 8, user_num=3)
+    with pytest.raises(ValueError):
+        ops.inference_svd(u, i, 10, 10, 8, loss="hinge")
+
+
+def test_sigmoid_helper():
+    assert ops.sigmoid(0.0) == 0.5
+    assert np.allclose(ops.sigmoid(np.array([-2.0, 2.0])).sum(), 1.0)
+
+
+def test_run_without_model_or_init_is_an_error():
+    with pytest.raises(RuntimeError):
+        tf.Session().run(tf.global_variables_initializer())

@@ -1,0 +1,187 @@
+"""The oracle pinned against everything available offline: the committed golden
+vectors, torch-CPU float64 autograd (independent derivation of the gradients), the explicit
+FM pairwise sum, and the C restatement against the NumPy one.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import svd_oracle as so
+from tests.util import dup_heavy_ids, make_oracle, rand_tables, rel_err
+
+
+def test_goldens_reproduce(golden):
+    """make_golden.py is deterministic: regenerating part 1 in memory gives the committed values."""
+    g = golden("svd_forward_grad.npz")
+    key = "U50_I40_D15_B64"
+    t = {k: g["%s/%s" % (key, k)].astype(np.float64) for k in ("mu", "bu", "bi", "P", "Q")}
+    u, i = g[key + "/u"], g[key + "/i"]
+    for loss in ("mse", "nll"):
+        r = g["%s/r_%s" % (key, loss)].astype(np.float64)
+        for ia in (0, 1):
+            for rb in (0, 1):
+                tag = "%s/%s_abs%d_rb%d" % (key, loss, ia, rb)
+                lg = so.forward(t["P"], t["Q"], t["bu"], t["bi"], t["mu"], u, i, bool(ia))
+                assert np.array_equal(lg, g[tag + "/logits"])
+                assert so.data_loss(lg, r, loss) == g[tag + "/loss"]
+                assert so.regularizer(t["P"], t["Q"], t["bu"], t["bi"], u, i, bool(rb)) == g[tag + "/reg"]
+                gk = so.dlogits(lg, r, loss)
+                dP, dQ, dbu, dbi, dmu = so.occurrence_grads(t["P"], t["Q"], t["bu"], t["bi"], u, i, gk, 0.05, bool(ia), bool(rb))
+                uq, inv = so.dedup(u)
+                assert np.array_equal(uq, g[tag + "/uniq_u"])
+                assert np.array_equal(so.segment_sum(dP, inv, uq.size), g[tag + "/gP"])
+
+
+@pytest.mark.parametrize("loss", ["mse", "nll"])
+@pytest.mark.parametrize("item_abs", [False, True])
+@pytest.mark.parametrize("reg_bias", [False, True])
+def test_gradients_match_torch_autograd(loss, item_abs, reg_bias):
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(1)
+    U, I, D, B, lam = 7, 5, 3, 16, 0.07
+    P, Q, bu, bi, mu = rs.normal(size=(U, D)), rs.normal(size=(I, D)), rs.normal(size=U), rs.normal(size=I), np.array(0.3)
+    u, i = rs.randint(0, U, B), rs.randint(0, I, B)
+    r = (rs.rand(B) > 0.5).astype(float) if loss == "nll" else rs.uniform(1, 5, B)
+    logits = so.forward(P, Q, bu, bi, mu, u, i, item_abs)
+    g = so.dlogits(logits, r, loss)
+    dP, dQ, dbu, dbi, dmu = so.occurrence_grads(P, Q, bu, bi, u, i, g, lam, item_abs, reg_bias)
+
+    def dense(occ, ids, n):
+        uq, inv = so.dedup(ids)
+        out = np.zeros((n,) + occ.shape[1:])
+        out[uq] = so.segment_sum(occ, inv, uq.size)
+        return out
+    tP, tQ, tbu, tbi, tmu = [torch.tensor(x, requires_grad=True) for x in (P, Q, bu, bi, mu)]
+    tu, ti, tr = torch.tensor(u), torch.tensor(i), torch.tensor(r)
+    pu, qi = tP[tu], tQ[ti]
+    x = (pu * (qi.abs() if item_abs else qi)).sum(1) + tmu + tbu[tu] + tbi[ti]
+    reg = 0.5 * (pu ** 2).sum() + 0.5 * (qi ** 2).sum()
+    if reg_bias:
+        reg = reg + 0.5 * (tbu[tu] ** 2).sum() + 0.5 * (tbi[ti] ** 2).sum()
+    data = 0.5 * ((x - tr) ** 2).sum() if loss == "mse" else \
+        torch.nn.functional.binary_cross_entropy_with_logits(x, tr, reduction="sum")
+    (data + lam * reg).backward()
+    assert np.abs(dense(dP, u, U) - tP.grad.numpy()).max() < 1e-12
+    assert np.abs(dense(dQ, i, I) - tQ.grad.numpy()).max() < 1e-12
+    assert np.abs(dense(dbu, u, U) - tbu.grad.numpy()).max() < 1e-12
+    assert np.abs(dense(dbi, i, I) - tbi.grad.numpy()).max() < 1e-12
+    assert abs(dmu - tmu.grad.item()) < 1e-12
+    assert abs(so.data_loss(logits, r, loss) - data.item()) < 1e-12
+    assert abs(so.regularizer(P, Q, bu, bi, u, i, reg_bias) - reg.item()) < 1e-12
+
+
+def test_tf1_adam_matches_torch_adam_on_dense_gradients():
+    """TF1's sparse Adam is dense over the table: with eps_hat placement aside it is
+    torch.optim.Adam on the densified gradient - checked over 5 steps with duplicate ids."""
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(3)
+    U, I, D, B = 9, 6, 4, 20
+    t = rand_tables(rs, U, I, D)
+    orc = make_oracle(U, I, D, t, optimizer="adam", adam_mode="tf1", lr=1e-2, reg=0.03)
+    params = [torch.tensor(np.asarray(t[k], np.float64), requires_grad=True) for k in ("mu", "bu", "bi", "P", "Q")]
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 1e-2
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    for step in range(1, 6):
+        u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+        r = rs.randint(1, 6, B).astype(np.float64)
+        orc.train_step(u, i, r)
+        mu_, bu_, bi_, P_, Q_ = params
+        tu, ti = torch.tensor(u.astype(np.int64)), torch.tensor(i.astype(np.int64))
+        x = (P_[tu] * Q_[ti]).sum(1) + mu_ + bu_[tu] + bi_[ti]
+        cost = 0.5 * ((x - torch.tensor(r)) ** 2).sum() + 0.03 * (0.5 * (P_[tu] ** 2).sum() + 0.5 * (Q_[ti] ** 2).sum())
+        grads = torch.autograd.grad(cost, params)
+        a = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)       # TF's lr_t with epsilon-hat
+        with torch.no_grad():
+            for p, g, mm, vv in zip(params, grads, m, v):
+                mm.mul_(b1).add_(g, alpha=1 - b1)
+                vv.mul_(b2).add_(g * g, alpha=1 - b2)
+                p.sub_(a * mm / (vv.sqrt() + eps))
+    for p, k in zip(params, (so.MU, so.BU, so.BI, so.PF, so.QF)):
+        assert rel_err(orc.tables()[k], p.detach().numpy()) < 1e-10
+
+
+def test_lazy_adam_only_touches_batch_rows_and_sgd_accumulates_duplicates():
+    rs = np.random.RandomState(4)
+    U, I, D, B = 30, 20, 5, 12
+    t = rand_tables(rs, U, I, D)
+    u, i = rs.randint(0, 10, B), rs.randint(0, 8, B)
+    r = rs.randint(1, 6, B).astype(np.float64)
+    lazy = make_oracle(U, I, D, t, optimizer="adam", adam_mode="lazy")
+    lazy.train_step(u, i, r)
+    untouched = np.setdiff1d(np.arange(U), u)
+    assert np.array_equal(lazy.P[untouched], np.asarray(t["P"], np.float64)[untouched])
+    assert not np.array_equal(lazy.P[np.unique(u)], np.asarray(t["P"], np.float64)[np.unique(u)])
+    # second step: tf1 moves rows that are NOT in the batch (momentum), lazy does not
+    tf1 = make_oracle(U, I, D, t, optimizer="adam", adam_mode="tf1")
+    tf1.train_step(u, i, r)
+    before = tf1.P.copy()
+    u2, i2 = rs.randint(10, 20, B), rs.randint(8, 16, B)
+    tf1.train_step(u2, i2, r)
+    assert not np.array_equal(tf1.P[np.unique(u)], before[np.unique(u)])
+    # SGD with all-identical ids: the row moves by lr * sum of the B occurrence gradients
+    sgd = make_oracle(U, I, D, t, optimizer="sgd", lr=1e-3, reg=0.0)
+    uu, ii = np.full(B, 3), np.full(B, 2)
+    lg = sgd.forward(uu, ii)
+    P0, Q0 = sgd.P.copy(), sgd.Q.copy()
+    sgd.train_step(uu, ii, r)
+    assert np.allclose(P0[3] - sgd.P[3], 1e-3 * np.sum(lg - r) * Q0[2], rtol=1e-12)
+
+
+def test_out_of_range_ids_raise():
+    orc = so.SvdOracle(5, 4, 3)
+    with pytest.raises(IndexError):
+        orc.forward([5], [0])
+    with pytest.raises(IndexError):
+        orc.train_step([0], [-1], [1.0])
+
+
+def test_head_rounds_half_to_even_and_rmse():
+    assert np.array_equal(so.head(np.array([0.0, 1e-9, -1e-9, 3.0, -3.0]), "nll"), [0.0, 1.0, 0.0, 1.0, 0.0])
+    assert so.rmse(np.array([1.0, 2.0]), np.array([2.0, 4.0])) == pytest.approx(np.sqrt(2.5))
+
+
+def test_c_restatement_matches_numpy_oracle():
+    COracle = pytest.importorskip("oracle.c_oracle").COracle
+    try:
+        from oracle import c_oracle
+        c_oracle.load()
+    except ImportError:
+        pytest.skip("oracle/libsvd_oracle.so not built")
+    rs = np.random.RandomState(0)
+    U, I, D, B = 200, 150, 20, 300
+    cases = (dict(optimizer="adam", adam_mode="tf1"), dict(optimizer="adam", adam_mode="lazy"),
+             dict(optimizer="sgd", loss="nll", item_abs=True, reg_bias=True),
+             dict(optimizer="adam", adam_mode="tf1", loss="nll", reg_bias=True))
+    for kw in cases:
+        t = rand_tables(rs, U, I, D)
+        o = make_oracle(U, I, D, t, **kw)
+        c = COracle(U, I, D, **kw)
+        c.set_tables(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        for s in range(5):
+            u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+            r = (rs.rand(B) < .5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, B).astype(np.float32)
+            a, b = o.train_step(u, i, r), c.train_step(u, i, r)
+            assert rel_err(b[0], a[0]) < 5e-6 and rel_err(b[1], a[1]) < 5e-6 and rel_err(b[2], a[2]) < 1e-5
+        for k in range(5):
+            assert rel_err(c.table(k), o.tables()[k]) < 1e-5
+        assert c.step == 5
+        with pytest.raises(IndexError):
+            c.train_step(np.array([U]), np.array([0]), np.array([1.0]))
+        c.close()
+
+
+def test_fm_forward_matches_pairwise_sum_and_golden(golden):
+    g = golden("fm_forward.npz")
+    for key in sorted({k.split("/")[0] for k in g.files}):
+        V, W, mu = g[key + "/V"].astype(np.float64), g[key + "/W"].astype(np.float64), float(g[key + "/mu"])
+        indptr, indices, data = g[key + "/indptr"], g[key + "/indices"], g[key + "/data"].astype(np.float64)
+        y = so.fm_forward(mu, W, V, indptr, indices, data)
+        assert np.allclose(y, g[key + "/y"], rtol=1e-13, atol=1e-13)
+        for row in range(0, len(indptr) - 1, 7):                       # explicit sum_{a<b} x_a x_b <V_a, V_b>
+            f, x = indices[indptr[row]:indptr[row + 1]], data[indptr[row]:indptr[row + 1]]
+            pair = sum(x[a] * x[b] * V[f[a]].dot(V[f[b]]) for a in range(len(f)) for b in range(a + 1, len(f)))
+            assert abs(y[row] - (mu + x.dot(W[f]) + pair)) < 1e-11
+        yref = so.fm_forward_reference_form(mu, W, V, indptr, indices, data)    # forward.py:22 literally
+        if key.endswith("binary"):
+            assert np.allclose(y, yref, rtol=1e-12, atol=1e-12)           # coincide on 0/1 features
+        else:
+            assert not np.allclose(y, yref, rtol=1e-3)                    # and differ on counts (SURVEY 8c ii)

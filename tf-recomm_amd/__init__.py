@@ -8,5 +8,6 @@ kernels behind the C-ABI of include/tfrecomm.h.  Import as ``import tfrecomm_amd
 from . import _lib
 from ._lib import TfrError, OutOfRangeError
 from .engine import SvdModel
+from . import dataio, graph, ops, config
 
-__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib"]
+__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config"]
