@@ -114,7 +114,7 @@ def time_cpu_baseline(wl, train, ids, budget_s=12.0):
                        "scalar restatement of the svd_train_val.py step (TensorFlow unavailable)" % (nsteps, el))
 
 
-def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, D=128, B=262144):
+def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, D=128, B=262144, sequential=False):
     """BASELINE configs[2] shape, forward only: achieved algorithmic GB/s of the gather-dot."""
     import tfrecomm_amd as T
     import torch
@@ -125,6 +125,9 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
     nb = 8
     du = torch.randint(0, U, (nb, B), dtype=torch.int32, device="cuda", generator=g)
     di = torch.randint(0, I, (nb, B), dtype=torch.int32, device="cuda", generator=g)
+    if sequential:      # diagnostic: perfectly streaming rows
+        du = (torch.arange(nb * B, device="cuda", dtype=torch.int64) % U).to(torch.int32).reshape(nb, B).contiguous()
+        di = (torch.arange(nb * B, device="cuda", dtype=torch.int64) % I).to(torch.int32).reshape(nb, B).contiguous()
     out = torch.empty(B, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     for s in range(warmup):
@@ -141,10 +144,25 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
     m.close()
     per_launch = B * (8 * D + 20)
     gbs = per_launch / (ms / n * 1e-3) / 1e9
-    return dict(kernel="k_forward<32,4,infer>", workload="10M users x 1M items, dim=128, batch=262144, uniform ids",
+    chk = float(out.double().sum().item())
+    # same-device calibration: what a plain 1 GiB device copy (read+write) reaches here
+    x = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+    y = torch.empty_like(x)
+    for _ in range(3):
+        y.copy_(x)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+    ev[0].record()
+    for i in range(10):
+        y.copy_(x)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    copy_gbs = 2 * x.numel() * 4 / (min(ev[i].elapsed_time(ev[i + 1]) for i in range(10)) * 1e-3) / 1e9
+    del x, y
+    return dict(checksum=chk, kernel="k_forward<32,4,infer>", workload="10M users x 1M items, dim=128, batch=262144, uniform ids",
                 bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None,
                 algorithmic_bytes_per_launch=per_launch, avg_launch_us=ms / n * 1e3,
-                ratings_per_s=B * n / (ms * 1e-3), wall_ratings_per_s=B * steps / wall)
+                ratings_per_s=B * n / (ms * 1e-3), wall_ratings_per_s=B * steps / wall,
+                device_copy_GBps=copy_gbs, frac_of_device_copy=gbs / copy_gbs)
 
 
 def main():
@@ -157,6 +175,12 @@ def main():
     ap.add_argument("--store-ratings", type=int, default=None, help="override the size of the rating store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--only-north-star", action="store_true", help="just the dim=128 forward roofline run")
+    ap.add_argument("--ns-users", type=int, default=10_000_000)
+    ap.add_argument("--ns-items", type=int, default=1_000_000)
+    ap.add_argument("--ns-batch", type=int, default=262144)
+    ap.add_argument("--ns-dim", type=int, default=128)
+    ap.add_argument("--ns-sequential", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,6 +199,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.only_north_star:
+        print(json.dumps(north_star_forward(local_rank, steps=args.steps, warmup=args.warmup, U=args.ns_users,
+                                            I=args.ns_items, B=args.ns_batch, D=args.ns_dim, sequential=args.ns_sequential)), flush=True)
+        return
     wl = dict(WORKLOADS[args.workload])
     if args.adam_mode:
         wl["adam_mode"] = args.adam_mode

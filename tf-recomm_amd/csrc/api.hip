@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <new>
 #include <vector>
@@ -179,7 +180,7 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     if ((rc = dmalloc(&m->gbp, cap))) return rc;
     if (tf1_ws)
         if ((rc = dmalloc(&m->gp, (size_t)cap * m->D))) return rc;
-    if ((rc = dmalloc(&m->partials, (size_t)2048 * 4))) return rc;
+    if ((rc = dmalloc(&m->partials, (size_t)8192 * 4))) return rc;
     if ((1 << (m->bits_u > m->bits_i ? m->bits_u : m->bits_i)) <= CSORT_MAX_BINS) {
         const size_t ntiles = (size_t)(cap + CSORT_TILE - 1) / CSORT_TILE;
         if ((rc = dmalloc(&m->lrank_u, cap))) return rc;

@@ -18,18 +18,25 @@ namespace tfr {
 // ------------------------------------------------------------------------------------
 template <int VEC> struct Frag { float v[VEC]; };
 
-template <int VEC>
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// NT: non-temporal (streaming) load - rows that are read once should not displace the
+// small, re-used tables (biases, ids) from L2 / Infinity Cache.
+template <int VEC, bool NT = false>
 __device__ __forceinline__ Frag<VEC> load_frag(const float* __restrict__ row, int d0, int D) {
     Frag<VEC> f;
     if constexpr (VEC == 4) {
         if (d0 < D) {
-            const float4 t = *reinterpret_cast<const float4*>(row + d0);
+            floatx4 t;
+            if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(row + d0));
+            else t = *reinterpret_cast<const floatx4*>(row + d0);
             f.v[0] = t.x; f.v[1] = t.y; f.v[2] = t.z; f.v[3] = t.w;
         } else {
             f.v[0] = f.v[1] = f.v[2] = f.v[3] = 0.f;
         }
     } else {
-        f.v[0] = (d0 < D) ? row[d0] : 0.f;
+        if constexpr (NT) f.v[0] = (d0 < D) ? __builtin_nontemporal_load(row + d0) : 0.f;
+        else f.v[0] = (d0 < D) ? row[d0] : 0.f;
     }
     return f;
 }
@@ -99,47 +106,58 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
     const int d0 = gl * VEC;
     const int D = a.D;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t stride = (int64_t)gridDim.x * 4 * SPI;
     const float mu = *a.mu;
 
     float acc[3] = {0.f, 0.f, 0.f};    // TRAIN: loss, reg, sum g | EVAL: sse, n_equal, -
     bool oob = false, oob_store = false;
 
-    for (int64_t base = wave_id * SPI; base < a.B; base += nwaves * SPI) {
-        int64_t k[UNR];
-        int32_t u[UNR], it[UNR];
-        bool ok[UNR];
-        float rr[UNR];
+    // The ids of iteration n+1 are fetched while the rows of iteration n are in flight, so the
+    // only exposed memory round trip per iteration is the row gather itself.
+    int32_t u_n[UNR], it_n[UNR];
+    float rr_n[UNR];
+    auto fetch_ids = [&](int64_t base) {
         if (a.ids) {
             // fused ShuffleIterator gather (dataio.py:115-117): id -> (user, item, rate) from the
-            // HBM-resident store; the gathered ids are kept for the backward
+            // HBM-resident store
             int64_t id[UNR];
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
-                k[j] = base + j * SPW + sub;
-                ok[j] = k[j] < a.B;
-                id[j] = ok[j] ? a.ids[k[j]] : 0;
+                const int64_t k = base + j * SPW + sub;
+                id[j] = (k < a.B) ? a.ids[k] : 0;
                 if ((uint64_t)id[j] >= (uint64_t)a.N) { oob_store = true; id[j] = 0; }
             }
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
-                u[j] = a.su[id[j]];
-                it[j] = a.si[id[j]];
-                rr[j] = a.sr[id[j]];
-                if (gl == 0 && ok[j]) { a.u_out[k[j]] = u[j]; a.it_out[k[j]] = it[j]; }
+                u_n[j] = a.su[id[j]];
+                it_n[j] = a.si[id[j]];
+                rr_n[j] = a.sr[id[j]];
             }
         } else {
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
-                k[j] = base + j * SPW + sub;
-                ok[j] = k[j] < a.B;
-                u[j] = ok[j] ? a.u[k[j]] : 0;
-                it[j] = ok[j] ? a.it[k[j]] : 0;
-                rr[j] = (MODE != MODE_INFER && ok[j]) ? a.r[k[j]] : 0.f;
+                const int64_t k = base + j * SPW + sub;
+                const bool ok = k < a.B;
+                u_n[j] = ok ? a.u[k] : 0;
+                it_n[j] = ok ? a.it[k] : 0;
+                rr_n[j] = (MODE != MODE_INFER && ok) ? a.r[k] : 0.f;
             }
         }
+    };
+
+    int64_t base = wave_id * SPI;
+    if (base < a.B) fetch_ids(base);
+    for (; base < a.B; base += stride) {
+        int64_t k[UNR];
+        int32_t u[UNR], it[UNR];
+        bool ok[UNR];
+        float rr[UNR];
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
+            k[j] = base + j * SPW + sub;
+            ok[j] = k[j] < a.B;
+            u[j] = u_n[j]; it[j] = it_n[j]; rr[j] = rr_n[j];
+            if (a.ids && gl == 0 && ok[j]) { a.u_out[k[j]] = u[j]; a.it_out[k[j]] = it[j]; }   // kept for the backward
             if ((uint64_t)(int64_t)u[j] >= (uint64_t)a.U) { oob = true; u[j] = 0; }
             if ((uint64_t)(int64_t)it[j] >= (uint64_t)a.I) { oob = true; it[j] = 0; }
         }
@@ -152,6 +170,7 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
             bu_[j] = a.bu[u[j]];
             bi_[j] = a.bi[it[j]];
         }
+        if (base + stride < a.B) fetch_ids(base + stride);      // next iteration's ids, behind the rows
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             float s = 0.f, sq = 0.f;
@@ -545,7 +564,7 @@ static void launch_forward_mode(const FwdArgs& a, int G, int VEC, int grid, hipS
 int forward_grid(int64_t B, int G) {
     const int64_t per_block = 4 * (64 / G) * 4;         // waves * SPW * UNR
     int64_t nb = (B + per_block - 1) / per_block;
-    if (nb > 2048) nb = 2048;                            // 256 CUs x 8 blocks, then grid-stride
+    if (nb > 8192) nb = 8192;                            // then grid-stride (measured: 8192 >= 2048 cap)
     if (nb < 1) nb = 1;
     return (int)nb;
 }
