@@ -142,6 +142,30 @@ int tfr_get_stream(tfr_model* m, void** hip_stream);
 /* last step's device scalars {loss, reg, sum_g} without a host copy */
 int tfr_scalars_devptr(tfr_model* m, void** ptr);
 
+/* ---- row-sharded building blocks: the same kernels, split so the host can put
+ *      an RCCL all-to-all between them.  The handle holds ONE rank's shard (user_num /
+ *      item_num = local row counts); bias_global is replicated.  All pointers are device
+ *      pointers; calls are asynchronous on the model's stream.
+ *      Semantics per rank and step (ops.py:143-149 applied to the rows this rank owns):
+ *        1. owners answer row requests:                  tfr_gather_item_rows
+ *        2. forward + backward on the rank's samples (user rows local, item rows fetched and
+ *           addressed by slot); user rows are updated in place, item-row gradients (one per
+ *           slot, already reduced over this rank's samples) are emitted: tfr_shard_forward_reduce
+ *        3. owners add the gradient rows received from all ranks (in rank order) and apply the
+ *           optimiser to their item rows:                tfr_shard_apply_items
+ *        4. with the all-reduced {loss, reg, sum_g}: bias_global update, beta powers,
+ *           global_step:                                 tfr_shard_finish_step            */
+int tfr_gather_item_rows(tfr_model* m, const int32_t* d_item_local, int64_t n, float* d_rows,
+                         float* d_bias);
+int tfr_shard_forward_reduce(tfr_model* m, const int32_t* d_user_local, const int32_t* d_item_slot,
+                             const float* d_rate, int64_t batch,
+                             const float* d_item_rows, const float* d_item_bias, int64_t n_item_rows,
+                             float* d_logits /* may be NULL */, float* d_item_row_grad,
+                             float* d_item_bias_grad, float* d_scalars4 /* out: loss, reg, sum_g, - */);
+int tfr_shard_apply_items(tfr_model* m, const int32_t* d_item_local, const float* d_grad,
+                          const float* d_bias_grad, int64_t n_rows);
+int tfr_shard_finish_step(tfr_model* m, const float* d_scalars4 /* global sums */);
+
 /* ---- index work of the backward, exposed for bit-exact checks: stable sort of batch
  *      positions by row id (what tf.unique + unsorted_segment_sum's batch-order walk reduce
  *      to).  side 0 = user ids, 1 = item ids.  Host pointers; outputs [batch]. */

@@ -1,0 +1,67 @@
+"""The row-sharded step with the REAL kernels: two processes (gloo, exchange staged through host
+memory) sharing the box's single GPU, against the float64 oracle and the single-GPU path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.util import RTOL, dup_heavy_ids, make_oracle, rand_tables, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kw, U, I, D, B, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfrecomm_amd import sharded, _lib as L
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        rs = np.random.RandomState(11)
+        t = rand_tables(rs, U, I, D)
+        ref = make_oracle(U, I, D, t, **kw)
+        comm = sharded.Comm()
+        m = sharded.ShardedSvd(U, I, D, comm, lambda ur, ir, d: sharded.HipShard(ur, ir, d, 0, **kw), device=dev)
+        m.set_tables_from_global(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        for s in range(steps):
+            u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+            r = (rs.rand(B) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, B).astype(np.float32)
+            logits, mine, scal = m.train_step(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev),
+                                              torch.from_numpy(r).to(dev))
+            wl, wloss, wreg = ref.train_step(u, i, r)
+            tol = RTOL * (s + 1)
+            own = mine.cpu().numpy()
+            assert rel_err(logits.cpu().numpy(), wl[own]) <= tol, "logits step %d" % s
+            sc = scal.cpu().numpy()
+            assert abs(sc[0] - wloss) <= tol * abs(wloss) and abs(sc[1] - wreg) <= tol * abs(wreg)
+        m.backend.sync()
+        got = m.gather_global_tables()
+        for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+            assert rel_err(got[tid], ref.tables()[tid]) <= RTOL * steps, "table %d" % tid
+        assert m.backend.model.step == steps
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(optimizer="adam", adam_mode="tf1"), dict(optimizer="adam", adam_mode="lazy"),
+                                dict(optimizer="sgd", loss="nll", item_abs=True, reg_bias=True, lr=5e-3, reg=0.01)])
+def test_two_rank_sharded_step_matches_oracle(kw):
+    mp.spawn(_worker, args=(2, _free_port(), kw, 500, 301, 64, 2000, 4), nprocs=2, join=True)
+
+
+def test_two_rank_d128_long_runs():
+    mp.spawn(_worker, args=(2, _free_port(), dict(optimizer="adam", adam_mode="lazy"), 40, 30, 128, 3000, 2),
+             nprocs=2, join=True)

@@ -1,0 +1,88 @@
+"""Row-sharded training under gloo, world_size 2 and 3, on CPU: the routing is
+integer-exact, and the sharded trajectory equals the single-rank oracle trajectory.  The kernels
+are replaced by an oracle-backed stand-in (tests/fake_shard_backend.py); the exchange code is
+the product's (tfrecomm_amd/sharded.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import svd_oracle as so
+from tests.util import dup_heavy_ids, make_oracle, rand_tables
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kw, U, I, D, B, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfrecomm_amd import sharded, _lib as L
+        from tests.fake_shard_backend import OracleShard
+        rs = np.random.RandomState(7)
+        t = rand_tables(rs, U, I, D)
+        ref = make_oracle(U, I, D, t, **kw)
+        comm = sharded.Comm()
+        m = sharded.ShardedSvd(U, I, D, comm, lambda ur, ir, d: OracleShard(ur, ir, d, **kw))
+        m.set_tables_from_global(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        for s in range(steps):
+            u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+            r = (rs.rand(B) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, B).astype(np.float32)
+            tu, ti, tr = torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(r)
+            logits, mine, scal = m.train_step(tu, ti, tr)
+            want_logits, want_loss, want_reg = ref.train_step(u, i, r)
+            # ---- routing: bit-exact integer work
+            p = m.last_plan
+            own = np.flatnonzero(u // m.per_u == rank)
+            assert np.array_equal(mine.numpy(), own)
+            assert np.array_equal(p["u_local"].numpy(), (u[own] - m.u_lo).astype(np.int32))
+            uq = np.unique(i[own])
+            assert np.array_equal(p["uniq"].numpy(), uq)
+            assert np.array_equal(uq[p["slot"].numpy()], i[own])
+            assert np.array_equal(p["send_counts"].numpy(), np.bincount(uq // m.per_i, minlength=world))
+            counts = [None] * world
+            dist.all_gather_object(counts, len(own))
+            assert sum(counts) == B                                   # every sample has exactly one owner
+            # ---- values
+            assert np.allclose(logits.numpy(), want_logits[own], rtol=1e-12, atol=1e-12)
+            assert abs(scal[0].item() - want_loss) <= 1e-10 * max(1.0, abs(want_loss))
+            assert abs(scal[1].item() - want_reg) <= 1e-10 * max(1.0, abs(want_reg))
+        got = m.gather_global_tables()
+        for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+            assert np.allclose(got[tid], ref.tables()[tid], rtol=1e-10, atol=1e-12), "table %d" % tid
+        with pytest.raises(IndexError):
+            m.plan(torch.tensor([U]), torch.tensor([0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kw", [dict(optimizer="adam", adam_mode="tf1"), dict(optimizer="adam", adam_mode="lazy"),
+                                dict(optimizer="sgd", loss="nll", item_abs=True, reg_bias=True, lr=5e-3, reg=0.01)])
+def test_sharded_equals_single_rank(world, kw):
+    # odd sizes: the last shard is shorter; U=50/world=3 -> 17,17,16
+    mp.spawn(_worker, args=(world, _free_port(), kw, 50, 31, 6, 120, 3), nprocs=world, join=True)
+
+
+def test_shard_ranges_cover_rows_exactly():
+    from tfrecomm_amd import sharded
+    for rows in (1, 7, 8, 100, 6040):
+        for world in (1, 2, 3, 8):
+            spans = [sharded.shard_range(rows, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == rows
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            per = sharded.rows_per_rank(rows, world)
+            for r, (lo, hi) in enumerate(spans):
+                ids = np.arange(lo, hi)
+                assert np.all(ids // per == r)

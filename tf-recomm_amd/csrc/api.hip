@@ -918,4 +918,232 @@ int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t B,
     return TFR_OK;
 }
 
+// ---- row-sharded building blocks --------------------------------------------
+// The model handle holds this rank's shard: user rows [U_local], item rows [I_local].  User
+// rows of a sample are always local (samples are routed to the owner of their user row);
+// item rows are fetched from their owners before, and item-row gradients returned after.
+
+static int bits_for_rows(int64_t rows) {
+    int b = 1;
+    while (((int64_t)1 << b) < rows && b < 31) ++b;
+    return b;
+}
+
+int tfr_gather_item_rows(tfr_model* m, const int32_t* d_item_local, int64_t n, float* d_rows, float* d_bias) {
+    MODEL_ENTER(m);
+    if (n < 0 || (n > 0 && (!d_item_local || !d_rows || !d_bias))) return fail(TFR_ERR_ARG, "gather_item_rows: bad arguments");
+    if (n == 0) return TFR_OK;
+    GatherRowsArgs g;
+    g.ids = d_item_local; g.table = m->w[TFR_Q]; g.bias = m->w[TFR_BI];
+    g.rows_out = d_rows; g.bias_out = d_bias; g.err = m->d_err; g.n = n; g.rows = m->I; g.D = m->D;
+    launch_gather_rows(g, m->G, m->VEC, m->stream);
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
+int tfr_shard_forward_reduce(tfr_model* m, const int32_t* du, const int32_t* dslot, const float* dr, int64_t B,
+                             const float* d_item_rows, const float* d_item_bias, int64_t nI,
+                             float* d_logits, float* d_item_row_grad, float* d_item_bias_grad,
+                             float* d_scalars4) {
+    MODEL_ENTER(m);
+    if (B < 0 || nI < 0 || !d_scalars4) return fail(TFR_ERR_ARG, "shard_forward_reduce: bad sizes / null scalars");
+    if (B > 0 && (!du || !dslot || !dr || !d_item_rows || !d_item_bias || !d_item_row_grad || !d_item_bias_grad || nI < 1))
+        return fail(TFR_ERR_ARG, "shard_forward_reduce: null pointer");
+    int rc;
+    if ((rc = ensure_capacity(m, B > nI ? (B > 0 ? B : 1) : nI))) return rc;
+    const tfr_opts& o = m->o;
+    const bool adam = o.optimizer == TFR_OPT_ADAM;
+    const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
+    const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
+    hipStream_t s = m->stream;
+    int nblk = 0;
+    if (B > 0) {
+        FwdArgs f;
+        memset(&f, 0, sizeof(f));
+        f.P = m->w[TFR_P]; f.Q = d_item_rows; f.bu = m->w[TFR_BU]; f.bi = d_item_bias; f.mu = m->w[TFR_MU];
+        f.u = du; f.it = dslot; f.r = dr; f.logits = d_logits; f.g = m->d_g; f.partials = m->partials; f.err = m->d_err;
+        f.B = B; f.U = m->U; f.I = nI;
+        f.D = m->D; f.loss = o.loss; f.item_abs = o.item_abs; f.reg_bias = o.reg_bias;
+        nblk = forward_grid(B, m->G);
+        {
+            Prof p(m, TFR_K_FORWARD);
+            launch_forward(f, MODE_TRAIN, m->G, m->VEC, nblk, s);
+        }
+        HIPCHK(hipGetLastError());
+        {
+            Prof p(m, TFR_K_SORT);
+            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, dslot, m->ks_i, m->iota, m->ps_i, B, bits_for_rows(nI), s));
+            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, du, m->ks_u, m->iota, m->ps_u, B, m->bits_u, s));
+        }
+        RedArgs r;
+        memset(&r, 0, sizeof(r));
+        r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
+        r.item_abs = o.item_abs; r.reg_bias = o.reg_bias;
+        r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
+        RedPair pr;
+        RedArgs ri = r;                 // item side: own = the fetched rows, indexed by slot
+        ri.side = 1;
+        ri.ks = m->ks_i; ri.ps = m->ps_i; ri.other = du;
+        ri.own = d_item_rows; ri.partner = m->w[TFR_P]; ri.own_bias = d_item_bias;
+        ri.grad_rows = m->gq; ri.grad_bias = m->gbq;
+        pr.a[0] = ri;
+        {
+            Prof p(m, TFR_K_REDUCE_ITEM);
+            launch_seg_reduce(pr, 1, RMODE_SCRATCH, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        ApplyArgs ap;
+        memset(&ap, 0, sizeof(ap));
+        ap.err = m->d_err; ap.B = B; ap.D = m->D;
+        ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
+        ApplyPair app;
+        app.a[0] = ap;                  // emit one reduced gradient row per slot
+        app.a[0].ks = m->ks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
+        app.a[0].w = d_item_row_grad; app.a[0].bias_w = d_item_bias_grad;
+        {
+            Prof p(m, TFR_K_APPLY);
+            launch_apply_rows(app, 1, 2, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        RedArgs ru = r;                 // user side: rows are local; partner = fetched item rows
+        ru.side = 0;
+        ru.ks = m->ks_u; ru.ps = m->ps_u; ru.other = dslot;
+        ru.own = m->w[TFR_P]; ru.partner = d_item_rows; ru.own_bias = m->w[TFR_BU];
+        ru.own_w = m->w[TFR_P]; ru.m = m->m[TFR_P]; ru.v = m->v[TFR_P];
+        ru.bias_w = m->w[TFR_BU]; ru.bias_m = m->m[TFR_BU]; ru.bias_v = m->v[TFR_BU];
+        ru.grad_bias = m->gbp; ru.map = tf1 ? m->map_u : nullptr;
+        ru.grad_rows = tf1 ? m->gp : m->gq + (size_t)m->cap * m->D;
+        ru.frozen_rows = (m->frozen >> TFR_P) & 1; ru.frozen_bias = (m->frozen >> TFR_BU) & 1;
+        pr.a[0] = ru;
+        {
+            Prof p(m, TFR_K_REDUCE_USER);
+            launch_seg_reduce(pr, 1, tf1 ? RMODE_SCRATCH : (adam ? RMODE_ADAM : RMODE_SGD), m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        if (!tf1) {
+            app.a[0] = ap;
+            app.a[0].only_split = 1;
+            app.a[0].ks = m->ks_u; app.a[0].grad_rows = ru.grad_rows; app.a[0].grad_bias = m->gbp;
+            app.a[0].w = m->w[TFR_P]; app.a[0].m = m->m[TFR_P]; app.a[0].v = m->v[TFR_P];
+            app.a[0].bias_w = m->w[TFR_BU]; app.a[0].bias_m = m->m[TFR_BU]; app.a[0].bias_v = m->v[TFR_BU];
+            app.a[0].frozen_rows = ru.frozen_rows; app.a[0].frozen_bias = ru.frozen_bias;
+            Prof p(m, TFR_K_APPLY);
+            launch_apply_rows(app, 1, adam ? 0 : 1, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (tf1) {                          // dense sweep of the local user rows (every row moves)
+        DensePair dp;
+        memset(&dp, 0, sizeof(dp));
+        DenseArgs& d = dp.a[0];
+        d.err = m->d_err; d.D = m->D; d.B = B;
+        d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps;
+        d.map = m->map_u; d.ks = m->ks_u; d.grad_rows = m->gp; d.grad_bias = m->gbp; d.rows = m->U;
+        d.w = m->w[TFR_P]; d.m = m->m[TFR_P]; d.v = m->v[TFR_P];
+        d.bias_w = m->w[TFR_BU]; d.bias_m = m->m[TFR_BU]; d.bias_v = m->v[TFR_BU];
+        d.frozen_rows = (m->frozen >> TFR_P) & 1; d.frozen_bias = (m->frozen >> TFR_BU) & 1;
+        Prof p(m, TFR_K_APPLY);
+        launch_adam_dense(dp, 1, m->G, m->VEC, s);
+        HIPCHK(hipGetLastError());
+    }
+    FinArgs f;                          // local {loss, reg, sum g}; bias_global waits for the all-reduce
+    memset(&f, 0, sizeof(f));
+    f.partials = m->partials; f.nblk = nblk; f.scalars = m->scalars; f.out = d_scalars4; f.err = m->d_err;
+    f.mu = m->w[TFR_MU];
+    {
+        Prof p(m, TFR_K_FINALIZE);
+        launch_finalize(f, s);
+    }
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
+int tfr_shard_apply_items(tfr_model* m, const int32_t* d_item_local, const float* d_grad, const float* d_bias_grad, int64_t n) {
+    MODEL_ENTER(m);
+    if (n < 0 || (n > 0 && (!d_item_local || !d_grad || !d_bias_grad))) return fail(TFR_ERR_ARG, "shard_apply_items: bad arguments");
+    int rc;
+    if ((rc = ensure_capacity(m, n > 0 ? n : 1))) return rc;
+    const tfr_opts& o = m->o;
+    const bool adam = o.optimizer == TFR_OPT_ADAM;
+    const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
+    const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
+    hipStream_t s = m->stream;
+    if (n > 0) {
+        {
+            Prof p(m, TFR_K_SORT);
+            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, d_item_local, m->ks_i, m->iota, m->ps_i, n, m->bits_i, s));
+        }
+        RedPair pr;
+        RedArgs& r = pr.a[0];
+        memset(&r, 0, sizeof(r));
+        r.err = m->d_err; r.B = n; r.D = m->D; r.side = 1;
+        r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
+        r.ks = m->ks_i; r.ps = m->ps_i; r.rows_in = d_grad; r.bias_in = d_bias_grad;
+        r.own = m->w[TFR_Q]; r.own_bias = m->w[TFR_BI];
+        r.own_w = m->w[TFR_Q]; r.m = m->m[TFR_Q]; r.v = m->v[TFR_Q];
+        r.bias_w = m->w[TFR_BI]; r.bias_m = m->m[TFR_BI]; r.bias_v = m->v[TFR_BI];
+        r.grad_rows = m->gq; r.grad_bias = m->gbq; r.map = tf1 ? m->map_i : nullptr;
+        r.frozen_rows = (m->frozen >> TFR_Q) & 1; r.frozen_bias = (m->frozen >> TFR_BI) & 1;
+        {
+            Prof p(m, TFR_K_REDUCE_ITEM);
+            launch_seg_reduce(pr, 1, tf1 ? RMODE_SCRATCH : (adam ? RMODE_ADAM : RMODE_SGD), m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        if (!tf1) {
+            ApplyPair app;
+            ApplyArgs& ap = app.a[0];
+            memset(&ap, 0, sizeof(ap));
+            ap.err = m->d_err; ap.B = n; ap.D = m->D; ap.only_split = 1;
+            ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
+            ap.ks = m->ks_i; ap.grad_rows = m->gq; ap.grad_bias = m->gbq;
+            ap.w = m->w[TFR_Q]; ap.m = m->m[TFR_Q]; ap.v = m->v[TFR_Q];
+            ap.bias_w = m->w[TFR_BI]; ap.bias_m = m->m[TFR_BI]; ap.bias_v = m->v[TFR_BI];
+            ap.frozen_rows = r.frozen_rows; ap.frozen_bias = r.frozen_bias;
+            Prof p(m, TFR_K_APPLY);
+            launch_apply_rows(app, 1, adam ? 0 : 1, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (tf1) {
+        DensePair dp;
+        memset(&dp, 0, sizeof(dp));
+        DenseArgs& d = dp.a[0];
+        d.err = m->d_err; d.D = m->D; d.B = n;
+        d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps;
+        d.map = m->map_i; d.ks = m->ks_i; d.grad_rows = m->gq; d.grad_bias = m->gbq; d.rows = m->I;
+        d.w = m->w[TFR_Q]; d.m = m->m[TFR_Q]; d.v = m->v[TFR_Q];
+        d.bias_w = m->w[TFR_BI]; d.bias_m = m->m[TFR_BI]; d.bias_v = m->v[TFR_BI];
+        d.frozen_rows = (m->frozen >> TFR_Q) & 1; d.frozen_bias = (m->frozen >> TFR_BI) & 1;
+        Prof p(m, TFR_K_APPLY);
+        launch_adam_dense(dp, 1, m->G, m->VEC, s);
+        HIPCHK(hipGetLastError());
+    }
+    return TFR_OK;
+}
+
+int tfr_shard_finish_step(tfr_model* m, const float* d_scalars4) {
+    MODEL_ENTER(m);
+    if (!d_scalars4) return fail(TFR_ERR_ARG, "shard_finish_step: null scalars");
+    const tfr_opts& o = m->o;
+    const bool adam = o.optimizer == TFR_OPT_ADAM;
+    const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.partials = d_scalars4; f.nblk = 1; f.scalars = m->scalars; f.out = nullptr;
+    f.mu = m->w[TFR_MU]; f.mu_m = m->m[TFR_MU]; f.mu_v = m->v[TFR_MU]; f.err = m->d_err;
+    f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
+    f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
+    {
+        Prof p(m, TFR_K_FINALIZE);
+        launch_finalize(f, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    if (adam) {
+        m->b1p *= o.beta1;
+        m->b2p *= o.beta2;
+    }
+    m->step += 1;
+    return TFR_OK;
+}
+
 }  // extern "C"

@@ -75,6 +75,7 @@ __device__ __forceinline__ int32_t tile_prefix(const int32_t* __restrict__ h, in
 __global__ __launch_bounds__(1024) void k_csort_scan(ScanFinArgs sa) {
     if (blockIdx.y == 2) { finalize_body(sa.f); return; }
     const CSortArgs& a = sa.c;
+    constexpr int MAXR = CSORT_MAX_BINS / 1024;          // rounds of 1024 bins
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
     const int col = blockIdx.y, tid = threadIdx.x;
@@ -84,35 +85,47 @@ __global__ __launch_bounds__(1024) void k_csort_scan(ScanFinArgs sa) {
     int32_t* __restrict__ binbase = a.binbase[col];
     const int lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nb; b0 += 1024) {
-        const int b = b0 + tid;
-        int32_t run = 0;
+    // phase A: per-bin tile prefixes for ALL of this thread's bins; no barrier in between, so the
+    // loads of different rounds overlap.  tot[r] = number of entries with key r*1024+tid.
+    int32_t tot[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int b = r * 1024 + tid;
+        tot[r] = 0;
         if (b < nb) {
-            if (nt <= 16) run = tile_prefix<16>(h, offs, nb, nt, b);
+            if (nt <= 16) tot[r] = tile_prefix<16>(h, offs, nb, nt, b);
             else {
+                int32_t run = 0;
                 for (int t = 0; t < nt; ++t) {
                     const int32_t v = h[(size_t)t * nb + b];
                     offs[(size_t)t * nb + b] = run;
                     run += v;
                 }
+                tot[r] = run;
             }
         }
-        // exclusive scan of `run` (this bin's total) over the 1024 bins of this round
-        int32_t incl = run;
+    }
+    __syncthreads();
+    // phase B: exclusive scan of the totals over all bins, 1024 bins per round (registers only)
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int32_t t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
+    for (int r = 0; r < MAXR; ++r) {
+        if (r * 1024 < nb) {                             // block-uniform
+            const int b = r * 1024 + tid;
+            int32_t incl = tot[r];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int32_t t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int32_t wbase = carry_s;
+            for (int w = 0; w < wave; ++w) wbase += wsum[w];
+            if (b < nb) binbase[b] = wbase + incl - tot[r];
+            __syncthreads();
+            if (tid == 1023) carry_s = wbase + incl;
+            __syncthreads();
         }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int32_t wbase = carry_s;
-        for (int w = 0; w < wave; ++w) wbase += wsum[w];
-        if (b < nb) binbase[b] = wbase + incl - run;
-        __syncthreads();
-        if (tid == 1023) carry_s = wbase + incl;
-        __syncthreads();
     }
 }
 

@@ -36,12 +36,20 @@ struct RedArgs {
     const float* own; const float* partner; const float* own_bias;
     float* own_w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
     float* grad_rows; float* grad_bias; int32_t* map;
+    const float* rows_in; const float* bias_in;    // sharded owner side: pre-reduced gradient rows
     const int32_t* err;
     int64_t B;
     int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;
     float lam, alpha, b1, b2, eps, lr;
 };
 struct RedPair { RedArgs a[2]; };
+
+struct GatherRowsArgs {
+    const int32_t* ids; const float* table; const float* bias;
+    float* rows_out; float* bias_out; int32_t* err;
+    int64_t n, rows;
+    int32_t D;
+};
 
 struct ApplyArgs {
     const int32_t* ks; const float* grad_rows; const float* grad_bias;
@@ -102,6 +110,7 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
 void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipStream_t s);
 void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s);
 void launch_gather(const GatherArgs& a, hipStream_t s);
+void launch_gather_rows(const GatherRowsArgs& a, int G, int VEC, hipStream_t s);
 void launch_iota(int32_t* p, int64_t n, hipStream_t s);
 void launch_finalize(const FinArgs& a, hipStream_t s);
 void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s);

@@ -236,6 +236,23 @@ __global__ __launch_bounds__(256) void k_gather_triples(GatherArgs a) {
     if (oob) atomicOr(a.err, 2);
 }
 
+// row fetch for a peer shard: rows_out[j] = table[ids[j]], bias_out[j] = bias[ids[j]]
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void k_gather_rows(GatherRowsArgs a) {
+    constexpr int GPB = 256 / G;
+    const int gl = threadIdx.x % G;
+    const int d0 = gl * VEC;
+    bool oob = false;
+    for (int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G; j < a.n; j += (int64_t)gridDim.x * GPB) {
+        int32_t id = a.ids[j];
+        if ((uint64_t)(int64_t)id >= (uint64_t)a.rows) { oob = true; id = 0; }
+        const Frag<VEC> f = load_frag<VEC>(a.table + (size_t)id * a.D, d0, a.D);
+        store_frag<VEC>(a.rows_out + (size_t)j * a.D, d0, a.D, f);
+        if (gl == 0) a.bias_out[j] = a.bias[id];
+    }
+    if (oob) atomicOr(a.err, 1);
+}
+
 __global__ __launch_bounds__(256) void k_iota(int32_t* p, int64_t n) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
          k += (int64_t)gridDim.x * blockDim.x)
@@ -303,7 +320,22 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     float ob = 0.f, tb = 0.f, mb = 0.f, vb = 0.f;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { o.v[q] = 0.f; t.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
-    if (valid) {
+    if (valid && a.rows_in) {
+        // owner side of the sharded step: the contribution is a gradient row already reduced by
+        // a peer (it includes that peer's lam * Q[i] terms); just add them up in arrival order
+        t = load_frag<VEC>(a.rows_in + (size_t)pos * D, d0, D);
+        tb = a.bias_in[pos];
+        o = load_frag<VEC>(a.own + roff, d0, D);
+        ob = a.own_bias[row];
+        if constexpr (RMODE == RMODE_ADAM) {
+            if (head) {
+                mrow = load_frag<VEC>(a.m + roff, d0, D);
+                vrow = load_frag<VEC>(a.v + roff, d0, D);
+                mb = a.bias_m[row];
+                vb = a.bias_v[row];
+            }
+        }
+    } else if (valid) {
         const float gk = a.g[pos];
         const int32_t pid = a.other[pos];
         const Frag<VEC> x = load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
@@ -423,6 +455,13 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
     Frag<VEC> w, mrow, vrow;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
+    if constexpr (OPT == 2) {                            // sharded step: emit the reduced gradient row
+        float gb2;
+        const Frag<VEC> tot = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, a.B, j, row, d0, D, gb2);
+        store_frag<VEC>(a.w + roff, d0, D, tot);
+        if (gl == 0) a.bias_w[row] = gb2;
+        return;
+    }
     if (!a.frozen_rows) {                                // issued before the piece walk
         w = load_frag<VEC>(a.w + roff, d0, D);
         if constexpr (OPT == 0) {
@@ -608,7 +647,8 @@ void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipSt
 #define TFR_APP_CASE(g, v)                                                                  \
     if (G == g && VEC == v) {                                                               \
         if (opt == 0) hipLaunchKernelGGL((k_apply_rows<g, v, 0>), grid, dim3(256), 0, s, p); \
-        else hipLaunchKernelGGL((k_apply_rows<g, v, 1>), grid, dim3(256), 0, s, p);         \
+        else if (opt == 1) hipLaunchKernelGGL((k_apply_rows<g, v, 1>), grid, dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((k_apply_rows<g, v, 2>), grid, dim3(256), 0, s, p);         \
         return;                                                                             \
     }
     TFR_APP_CASE(4, 4) TFR_APP_CASE(8, 4) TFR_APP_CASE(16, 4) TFR_APP_CASE(32, 4) TFR_APP_CASE(64, 4)
@@ -636,6 +676,18 @@ static int flat_grid(int64_t n) {
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     return (int)nb;
+}
+
+void launch_gather_rows(const GatherRowsArgs& a, int G, int VEC, hipStream_t s) {
+    const int gpb = 256 / G;
+    int64_t nb = (a.n + gpb - 1) / gpb;
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+#define TFR_GR_CASE(g, v) \
+    if (G == g && VEC == v) { hipLaunchKernelGGL((k_gather_rows<g, v>), dim3((int)nb), dim3(256), 0, s, a); return; }
+    TFR_GR_CASE(4, 4) TFR_GR_CASE(8, 4) TFR_GR_CASE(16, 4) TFR_GR_CASE(32, 4) TFR_GR_CASE(64, 4)
+    TFR_GR_CASE(4, 1) TFR_GR_CASE(8, 1) TFR_GR_CASE(16, 1) TFR_GR_CASE(32, 1) TFR_GR_CASE(64, 1)
+#undef TFR_GR_CASE
 }
 
 void launch_gather(const GatherArgs& a, hipStream_t s) {

@@ -180,6 +180,22 @@ class SvdModel:
     def train_step_dev(self, d_user, d_item, d_rate, batch, d_logits=None):
         L.check(self._lib.tfr_train_step_dev(self._h, d_user, d_item, d_rate, batch, d_logits))
 
+    # -- row-sharded building blocks (device pointers; see include/tfrecomm.h) ------
+    def gather_item_rows(self, d_item_local, n, d_rows, d_bias):
+        L.check(self._lib.tfr_gather_item_rows(self._h, d_item_local, n, d_rows, d_bias))
+
+    def shard_forward_reduce(self, d_user_local, d_item_slot, d_rate, batch, d_item_rows, d_item_bias,
+                             n_item_rows, d_logits, d_item_row_grad, d_item_bias_grad, d_scalars4):
+        L.check(self._lib.tfr_shard_forward_reduce(self._h, d_user_local, d_item_slot, d_rate, batch, d_item_rows,
+                                                   d_item_bias, n_item_rows, d_logits, d_item_row_grad,
+                                                   d_item_bias_grad, d_scalars4))
+
+    def shard_apply_items(self, d_item_local, d_grad, d_bias_grad, n):
+        L.check(self._lib.tfr_shard_apply_items(self._h, d_item_local, d_grad, d_bias_grad, n))
+
+    def shard_finish_step(self, d_scalars4):
+        L.check(self._lib.tfr_shard_finish_step(self._h, d_scalars4))
+
     def table_devptr(self, which):
         p, n = L._p(), C.c_int64()
         L.check(self._lib.tfr_table_devptr(self._h, which, C.byref(p), C.byref(n)))
