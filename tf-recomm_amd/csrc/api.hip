@@ -60,6 +60,7 @@ struct tfr_model {
     size_t sort_tmp_bytes = 0;
     int32_t *lrank_u = nullptr, *lrank_i = nullptr, *hist_u = nullptr, *hist_i = nullptr;   // csort
     int32_t *offs_u = nullptr, *offs_i = nullptr, *binbase_u = nullptr, *binbase_i = nullptr;
+    int32_t *blocktot_u = nullptr, *blocktot_i = nullptr;
     float *gq = nullptr, *gp = nullptr, *gbq = nullptr, *gbp = nullptr;
     int32_t *map_u = nullptr, *map_i = nullptr;
     float* partials = nullptr;
@@ -140,6 +141,8 @@ static void free_workspace(tfr_model* m) {
     dfree(m->sort_tmp); dfree(m->gq); dfree(m->gp); dfree(m->gbq); dfree(m->gbp);
     dfree(m->partials); dfree(m->lrank_u); dfree(m->lrank_i); dfree(m->hist_u); dfree(m->hist_i);
     dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
+    dfree(m->blocktot_u); dfree(m->blocktot_i);
+    m->blocktot_u = m->blocktot_i = nullptr;
     m->lrank_u = m->lrank_i = m->hist_u = m->hist_i = nullptr;
     m->offs_u = m->offs_i = m->binbase_u = m->binbase_i = nullptr;
     m->d_u = m->d_i = nullptr; m->d_r = m->d_logits = m->d_g = nullptr;
@@ -191,6 +194,8 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
         if ((rc = dmalloc(&m->offs_i, ((size_t)1 << m->bits_i) * ntiles))) return rc;
         if ((rc = dmalloc(&m->binbase_u, (size_t)1 << m->bits_u))) return rc;
         if ((rc = dmalloc(&m->binbase_i, (size_t)1 << m->bits_i))) return rc;
+        if ((rc = dmalloc(&m->blocktot_u, 64))) return rc;
+        if ((rc = dmalloc(&m->blocktot_i, 64))) return rc;
     }
     launch_iota(m->iota, cap, m->stream);
     HIPCHK(hipGetLastError());
@@ -510,6 +515,7 @@ static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int6
         c.ks[0] = m->ks_u; c.ks[1] = m->ks_i; c.ps[0] = m->ps_u; c.ps[1] = m->ps_i;
         c.lrank[0] = m->lrank_u; c.lrank[1] = m->lrank_i; c.hist[0] = m->hist_u; c.hist[1] = m->hist_i;
         c.offs[0] = m->offs_u; c.offs[1] = m->offs_i; c.binbase[0] = m->binbase_u; c.binbase[1] = m->binbase_i;
+        c.blocktot[0] = m->blocktot_u; c.blocktot[1] = m->blocktot_i;
         c.nbins[0] = 1 << m->bits_u; c.nbins[1] = 1 << m->bits_i;
         c.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
         c.B = B;

@@ -73,60 +73,45 @@ __device__ __forceinline__ int32_t tile_prefix(const int32_t* __restrict__ h, in
 }
 
 __global__ __launch_bounds__(1024) void k_csort_scan(ScanFinArgs sa) {
-    if (blockIdx.y == 2) { finalize_body(sa.f); return; }
+    if (blockIdx.y == 2) {                               // the step's finalize rides in this launch
+        if (blockIdx.x == 0) finalize_body(sa.f);
+        return;
+    }
     const CSortArgs& a = sa.c;
-    constexpr int MAXR = CSORT_MAX_BINS / 1024;          // rounds of 1024 bins
     __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s;
     const int col = blockIdx.y, tid = threadIdx.x;
     const int nb = a.nbins[col], nt = a.ntiles;
+    if ((int)blockIdx.x * 1024 >= nb) return;            // block-uniform
     const int32_t* __restrict__ h = a.hist[col];
     int32_t* __restrict__ offs = a.offs[col];
-    int32_t* __restrict__ binbase = a.binbase[col];
     const int lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    // phase A: per-bin tile prefixes for ALL of this thread's bins; no barrier in between, so the
-    // loads of different rounds overlap.  tot[r] = number of entries with key r*1024+tid.
-    int32_t tot[MAXR];
-#pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
-        const int b = r * 1024 + tid;
-        tot[r] = 0;
-        if (b < nb) {
-            if (nt <= 16) tot[r] = tile_prefix<16>(h, offs, nb, nt, b);
-            else {
-                int32_t run = 0;
-                for (int t = 0; t < nt; ++t) {
-                    const int32_t v = h[(size_t)t * nb + b];
-                    offs[(size_t)t * nb + b] = run;
-                    run += v;
-                }
-                tot[r] = run;
+    // phase A: this block's 1024 bins - per-bin prefix over the tiles
+    const int b = blockIdx.x * 1024 + tid;
+    int32_t tot = 0;
+    if (b < nb) {
+        if (nt <= 16) tot = tile_prefix<16>(h, offs, nb, nt, b);
+        else {
+            for (int t = 0; t < nt; ++t) {
+                const int32_t v = h[(size_t)t * nb + b];
+                offs[(size_t)t * nb + b] = tot;
+                tot += v;
             }
         }
     }
+    // phase B: exclusive scan of the bin totals inside the block; the block's grand total goes to
+    // blocktot[] and the scatter kernel adds the totals of the preceding blocks.
+    int32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    // phase B: exclusive scan of the totals over all bins, 1024 bins per round (registers only)
-#pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
-        if (r * 1024 < nb) {                             // block-uniform
-            const int b = r * 1024 + tid;
-            int32_t incl = tot[r];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int32_t t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += t;
-            }
-            if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
-            int32_t wbase = carry_s;
-            for (int w = 0; w < wave; ++w) wbase += wsum[w];
-            if (b < nb) binbase[b] = wbase + incl - tot[r];
-            __syncthreads();
-            if (tid == 1023) carry_s = wbase + incl;
-            __syncthreads();
-        }
-    }
+    int32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    if (b < nb) a.binbase[col][b] = wbase + incl - tot;
+    if (tid == 1023) a.blocktot[col][blockIdx.x] = wbase + incl;
 }
 
 // csort pass 3: scatter (key, batch position) to its sorted slot.
@@ -137,7 +122,9 @@ __global__ __launch_bounds__(CSORT_TILE) void k_csort_scatter(CSortArgs a) {
     const int32_t key = a.keys[col][k];
     const int nb = a.nbins[col];
     const int32_t bin = key & (nb - 1);
-    const int32_t dst = a.binbase[col][bin] + a.offs[col][(size_t)tile * nb + bin] + a.lrank[col][k];
+    int32_t base = 0;                                    // entries in the 1024-bin blocks before this one
+    for (int q = 0; q < (bin >> 10); ++q) base += a.blocktot[col][q];
+    const int32_t dst = base + a.binbase[col][bin] + a.offs[col][(size_t)tile * nb + bin] + a.lrank[col][k];
     a.ks[col][dst] = key;
     a.ps[col][dst] = (int32_t)k;
 }
@@ -162,7 +149,7 @@ void launch_csort(const CSortArgs& a, const FinArgs* fin, hipStream_t s) {
     ScanFinArgs sa;
     sa.c = a;
     if (fin) sa.f = *fin; else memset(&sa.f, 0, sizeof(sa.f));
-    hipLaunchKernelGGL(k_csort_scan, dim3(1, fin ? 3 : 2), dim3(1024), 0, s, sa);
+    hipLaunchKernelGGL(k_csort_scan, dim3((nbmax + 1023) / 1024, fin ? 3 : 2), dim3(1024), 0, s, sa);
     hipLaunchKernelGGL(k_csort_scatter, grid, dim3(CSORT_TILE), 0, s, a);
 }
 

@@ -86,7 +86,8 @@ struct CSortArgs {
     int32_t* lrank[2];           // [B] rank of the entry among equal keys inside its tile
     int32_t* hist[2];            // [ntiles * nbins], tile-major: per-tile key histogram
     int32_t* offs[2];            // [ntiles * nbins]: entries with this key in earlier tiles
-    int32_t* binbase[2];         // [nbins]: entries with a smaller key
+    int32_t* binbase[2];         // [nbins]: entries with a smaller key inside the bin's 1024-bin block
+    int32_t* blocktot[2];        // [nbins/1024]: entries per 1024-bin block
     int32_t nbins[2];            // power of two
     int32_t ntiles;
     int64_t B;
