@@ -115,8 +115,8 @@ int tfr_train_step(tfr_model* m, const int32_t* user, const int32_t* item, const
  *      (dataio.py:98-103,114-117) kept in HBM; the host still draws the ids. */
 int tfr_upload_triples(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
                        int64_t n);
-/* same, but the three columns are already in HBM (device pointers, borrowed: the caller keeps
- * them alive until the next upload / set / destroy). */
+/* same, but the three columns are already in HBM (device pointers; copied into the library's
+ * own 16-byte-record store, so the caller may free them after the call). */
 int tfr_set_triples_dev(tfr_model* m, const int32_t* d_user, const int32_t* d_item,
                         const float* d_rate, int64_t n);
 /* ids[step*batch + k] index the store: nsteps minibatches in one call.  loss_out[nsteps]

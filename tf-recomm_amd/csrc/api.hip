@@ -56,11 +56,11 @@ struct tfr_model {
     int32_t *d_u = nullptr, *d_i = nullptr;
     float *d_r = nullptr, *d_logits = nullptr, *d_g = nullptr;
     int32_t *iota = nullptr, *ks_u = nullptr, *ps_u = nullptr, *ks_i = nullptr, *ps_i = nullptr;
-    void* sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
+    int32_t *ks2_u = nullptr, *ps2_u = nullptr, *ks2_i = nullptr, *ps2_i = nullptr;   // rsort ping-pong
     int32_t *lrank_u = nullptr, *lrank_i = nullptr, *hist_u = nullptr, *hist_i = nullptr;   // csort
     int32_t *offs_u = nullptr, *offs_i = nullptr, *binbase_u = nullptr, *binbase_i = nullptr;
     int32_t *blocktot_u = nullptr, *blocktot_i = nullptr;
+    bool csort_ok = false;
     float *gq = nullptr, *gp = nullptr, *gbq = nullptr, *gbp = nullptr;
     int32_t *map_u = nullptr, *map_i = nullptr;
     float* partials = nullptr;
@@ -69,10 +69,8 @@ struct tfr_model {
     int64_t step_out_cap = 0;
     int32_t* d_err = nullptr;
     // resident store
-    int32_t *su = nullptr, *si = nullptr;
-    float* sr = nullptr;
+    int4* store = nullptr;            // {user, item, rate bits, -} per rating
     int64_t N = 0;
-    bool store_owned = false;
     int64_t* d_ids = nullptr;
     int64_t n_ids = 0;
     // profiling
@@ -138,7 +136,7 @@ static int drain_profile(tfr_model* m) {
 static void free_workspace(tfr_model* m) {
     dfree(m->d_u); dfree(m->d_i); dfree(m->d_r); dfree(m->d_logits); dfree(m->d_g);
     dfree(m->iota); dfree(m->ks_u); dfree(m->ps_u); dfree(m->ks_i); dfree(m->ps_i);
-    dfree(m->sort_tmp); dfree(m->gq); dfree(m->gp); dfree(m->gbq); dfree(m->gbp);
+    dfree(m->ks2_u); dfree(m->ps2_u); dfree(m->ks2_i); dfree(m->ps2_i); dfree(m->gq); dfree(m->gp); dfree(m->gbq); dfree(m->gbp);
     dfree(m->partials); dfree(m->lrank_u); dfree(m->lrank_i); dfree(m->hist_u); dfree(m->hist_i);
     dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
     dfree(m->blocktot_u); dfree(m->blocktot_i);
@@ -147,7 +145,7 @@ static void free_workspace(tfr_model* m) {
     m->offs_u = m->offs_i = m->binbase_u = m->binbase_i = nullptr;
     m->d_u = m->d_i = nullptr; m->d_r = m->d_logits = m->d_g = nullptr;
     m->iota = m->ks_u = m->ps_u = m->ks_i = m->ps_i = nullptr;
-    m->sort_tmp = nullptr; m->gq = m->gp = m->gbq = m->gbp = nullptr; m->partials = nullptr;
+    m->ks2_u = m->ps2_u = m->ks2_i = m->ps2_i = nullptr; m->gq = m->gp = m->gbq = m->gbp = nullptr; m->partials = nullptr;
     m->cap = 0;
 }
 
@@ -169,13 +167,10 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     if ((rc = dmalloc(&m->ps_u, cap))) return rc;
     if ((rc = dmalloc(&m->ks_i, cap))) return rc;
     if ((rc = dmalloc(&m->ps_i, cap))) return rc;
-    size_t tb = sort_temp_bytes(cap, m->bits_u);
-    size_t tb2 = sort_temp_bytes(cap, m->bits_i);
-    if (tb2 > tb) tb = tb2;
-    if (tb == 0) return fail(TFR_ERR_HIP, "radix sort temp-size query failed");
-    tb = 2 * tb + (1 << 20);          // head-room: smaller batches may pick another rocPRIM path
-    m->sort_tmp_bytes = tb;
-    HIPCHK(hipMalloc(&m->sort_tmp, tb));
+    if ((rc = dmalloc(&m->ks2_u, cap))) return rc;
+    if ((rc = dmalloc(&m->ps2_u, cap))) return rc;
+    if ((rc = dmalloc(&m->ks2_i, cap))) return rc;
+    if ((rc = dmalloc(&m->ps2_i, cap))) return rc;
     const bool tf1_ws = m->o.optimizer == TFR_OPT_ADAM && m->o.adam_mode == TFR_ADAM_TF1;
     // non-tf1: second half of gq parks the pieces of split user runs
     if ((rc = dmalloc(&m->gq, (size_t)cap * m->D * (tf1_ws ? 1 : 2)))) return rc;
@@ -184,18 +179,22 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     if (tf1_ws)
         if ((rc = dmalloc(&m->gp, (size_t)cap * m->D))) return rc;
     if ((rc = dmalloc(&m->partials, (size_t)8192 * 4))) return rc;
-    if ((1 << (m->bits_u > m->bits_i ? m->bits_u : m->bits_i)) <= CSORT_MAX_BINS) {
+    {
         const size_t ntiles = (size_t)(cap + CSORT_TILE - 1) / CSORT_TILE;
+        const bool small = (1 << (m->bits_u > m->bits_i ? m->bits_u : m->bits_i)) <= CSORT_MAX_BINS;
+        const size_t hu = (small ? ((size_t)1 << m->bits_u) : 256) * ntiles;
+        const size_t hi = (small ? ((size_t)1 << m->bits_i) : 256) * ntiles;
         if ((rc = dmalloc(&m->lrank_u, cap))) return rc;
         if ((rc = dmalloc(&m->lrank_i, cap))) return rc;
-        if ((rc = dmalloc(&m->hist_u, ((size_t)1 << m->bits_u) * ntiles))) return rc;
-        if ((rc = dmalloc(&m->hist_i, ((size_t)1 << m->bits_i) * ntiles))) return rc;
-        if ((rc = dmalloc(&m->offs_u, ((size_t)1 << m->bits_u) * ntiles))) return rc;
-        if ((rc = dmalloc(&m->offs_i, ((size_t)1 << m->bits_i) * ntiles))) return rc;
-        if ((rc = dmalloc(&m->binbase_u, (size_t)1 << m->bits_u))) return rc;
-        if ((rc = dmalloc(&m->binbase_i, (size_t)1 << m->bits_i))) return rc;
-        if ((rc = dmalloc(&m->blocktot_u, 64))) return rc;
-        if ((rc = dmalloc(&m->blocktot_i, 64))) return rc;
+        if ((rc = dmalloc(&m->hist_u, hu > 256 * ntiles ? hu : 256 * ntiles))) return rc;
+        if ((rc = dmalloc(&m->hist_i, hi > 256 * ntiles ? hi : 256 * ntiles))) return rc;
+        if ((rc = dmalloc(&m->offs_u, hu > 256 * ntiles ? hu : 256 * ntiles))) return rc;
+        if ((rc = dmalloc(&m->offs_i, hi > 256 * ntiles ? hi : 256 * ntiles))) return rc;
+        if ((rc = dmalloc(&m->binbase_u, small ? (size_t)1 << m->bits_u : 1))) return rc;
+        if ((rc = dmalloc(&m->binbase_i, small ? (size_t)1 << m->bits_i : 1))) return rc;
+        if ((rc = dmalloc(&m->blocktot_u, 64 + 256 * ntiles / 16384))) return rc;
+        if ((rc = dmalloc(&m->blocktot_i, 64 + 256 * ntiles / 16384))) return rc;
+        m->csort_ok = small;
     }
     launch_iota(m->iota, cap, m->stream);
     HIPCHK(hipGetLastError());
@@ -268,7 +267,7 @@ int tfr_destroy(tfr_model* m) {
     free_workspace(m);
     for (int t = 0; t < 5; ++t) { dfree(m->w[t]); dfree(m->m[t]); dfree(m->v[t]); }
     dfree(m->map_u); dfree(m->map_i); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
-    if (m->store_owned) { dfree(m->su); dfree(m->si); dfree(m->sr); }
+    dfree(m->store);
     dfree(m->d_ids);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
@@ -491,11 +490,11 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
     a.logits = d_logits; a.g = d_g; a.partials = m->partials; a.err = m->d_err;
     a.B = B; a.U = m->U; a.I = m->I; a.N = m->N;
     if (d_store_ids) {                 // fused gather from the resident store
-        a.ids = d_store_ids; a.su = m->su; a.si = m->si; a.sr = m->sr;
+        a.ids = d_store_ids; a.store = m->store;
         a.u_out = m->d_u; a.it_out = m->d_i;
     }
     a.D = m->D; a.loss = m->o.loss; a.item_abs = m->o.item_abs; a.reg_bias = m->o.reg_bias;
-    const int grid = forward_grid(B, m->G);
+    const int grid = forward_grid(B, m->G, mode);
     if (nblk_out) *nblk_out = grid;
     {
         Prof p(m, TFR_K_FORWARD);
@@ -505,11 +504,46 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
     return TFR_OK;
 }
 
+// hand-written LSD radix sort of one or two key columns: column c = (keys[c], bits[c]) ->
+// sorted keys in ks_out[c], original positions in ps_out[c].  ceil(maxbits/8) passes, 3 launches each.
+static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* keys, const int* bits,
+                              int32_t* const* ks_out, int32_t* const* ps_out, int64_t B) {
+    int maxbits = bits[0];
+    if (ncols > 1 && bits[1] > maxbits) maxbits = bits[1];
+    const int passes = (maxbits + 7) / 8;
+    int32_t* tmpk[2] = {m->ks2_u, m->ks2_i};
+    int32_t* tmpv[2] = {m->ps2_u, m->ps2_i};
+    RSortArgs r;
+    memset(&r, 0, sizeof(r));
+    r.B = B;
+    r.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+    r.lrank[0] = m->lrank_u; r.lrank[1] = m->lrank_i;
+    r.hist[0] = m->hist_u; r.hist[1] = m->hist_i;
+    r.offs[0] = m->offs_u; r.offs[1] = m->offs_i;
+    r.blocktot[0] = m->blocktot_u; r.blocktot[1] = m->blocktot_i;
+    r.chunk = 16384;                                     // 256*ntiles/16384 scan blocks (<= cap/64K + 1)
+    for (int p = 0; p < passes; ++p) {
+        const bool to_final = ((passes - 1 - p) % 2) == 0;      // last pass lands in ks_out / ps_out
+        for (int c = 0; c < ncols; ++c) {
+            if (p == 0) { r.keys_in[c] = keys[c]; r.vals_in[c] = nullptr; }
+            else { r.keys_in[c] = r.keys_out[c]; r.vals_in[c] = r.vals_out[c]; }
+        }
+        for (int c = 0; c < ncols; ++c) {
+            r.keys_out[c] = to_final ? ks_out[c] : tmpk[c];
+            r.vals_out[c] = to_final ? ps_out[c] : tmpv[c];
+        }
+        r.shift = 8 * p;
+        launch_rsort_pass(r, ncols, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
 // stable sort of batch positions by user id and by item id
 static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int64_t B,
                         const FinArgs* fin = nullptr, bool* fin_done = nullptr) {
     Prof p(m, TFR_K_SORT);
-    if (m->lrank_u && csort_eligible(B, m->bits_u, m->bits_i)) {
+    if (m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i)) {
         CSortArgs c;
         c.keys[0] = du; c.keys[1] = di;
         c.ks[0] = m->ks_u; c.ks[1] = m->ks_i; c.ps[0] = m->ps_u; c.ps[1] = m->ps_i;
@@ -522,11 +556,13 @@ static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int6
         launch_csort(c, fin, m->stream);
         if (fin && fin_done) *fin_done = true;
         HIPCHK(hipGetLastError());
-    } else {
-        HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, di, m->ks_i, m->iota, m->ps_i, B, m->bits_i, m->stream));
-        HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, du, m->ks_u, m->iota, m->ps_u, B, m->bits_u, m->stream));
+        return TFR_OK;
     }
-    return TFR_OK;
+    const int32_t* keys[2] = {du, di};
+    const int bits[2] = {m->bits_u, m->bits_i};
+    int32_t* ks[2] = {m->ks_u, m->ks_i};
+    int32_t* ps[2] = {m->ps_u, m->ps_i};
+    return radix_sort_columns(m, 2, keys, bits, ks, ps, B);
 }
 
 // one minibatch on device-resident (u, i, r) - or, with d_store_ids, on rows of the resident
@@ -767,36 +803,54 @@ int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float
 }
 
 // ---- resident store --------------------------------------------------------------------
-int tfr_upload_triples(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t N) {
-    MODEL_ENTER(m);
-    if (N < 1 || !u || !i || !r) return fail(TFR_ERR_ARG, "upload_triples: need n >= 1 and non-null columns");
+// pack three columns (host or device) into the 16-byte-record store, in chunks
+static int build_store(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t N, bool on_device) {
     HIPCHK(hipStreamSynchronize(m->stream));
-    if (m->store_owned) { dfree(m->su); dfree(m->si); dfree(m->sr); }
-    m->su = m->si = nullptr; m->sr = nullptr; m->N = 0;
-    m->store_owned = true;
+    dfree(m->store);
+    m->store = nullptr; m->N = 0;
     int rc;
-    if ((rc = dmalloc(&m->su, (size_t)N))) return rc;
-    if ((rc = dmalloc(&m->si, (size_t)N))) return rc;
-    if ((rc = dmalloc(&m->sr, (size_t)N))) return rc;
-    HIPCHK(hipMemcpyAsync(m->su, u, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipMemcpyAsync(m->si, i, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipMemcpyAsync(m->sr, r, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    if ((rc = dmalloc(&m->store, (size_t)N))) return rc;
+    if (on_device) {
+        launch_pack_triples(u, i, r, m->store, N, m->stream);
+        HIPCHK(hipGetLastError());
+    } else {
+        const int64_t chunk = (int64_t)1 << 24;
+        int32_t *tu = nullptr, *ti = nullptr;
+        float* tr = nullptr;
+        const int64_t c0 = N < chunk ? N : chunk;
+        if ((rc = dmalloc(&tu, (size_t)c0)) || (rc = dmalloc(&ti, (size_t)c0)) || (rc = dmalloc(&tr, (size_t)c0))) {
+            dfree(tu); dfree(ti); dfree(tr);
+            return rc;
+        }
+        hipError_t e = hipSuccess;
+        for (int64_t off = 0; off < N && e == hipSuccess; off += chunk) {
+            const int64_t n = (N - off < chunk) ? N - off : chunk;
+            e = hipMemcpyAsync(tu, u + off, (size_t)n * 4, hipMemcpyHostToDevice, m->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ti, i + off, (size_t)n * 4, hipMemcpyHostToDevice, m->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(tr, r + off, (size_t)n * 4, hipMemcpyHostToDevice, m->stream);
+            if (e == hipSuccess) {
+                launch_pack_triples(tu, ti, tr, m->store + off, n, m->stream);
+                e = hipStreamSynchronize(m->stream);
+            }
+        }
+        dfree(tu); dfree(ti); dfree(tr);
+        if (e != hipSuccess) return fail(TFR_ERR_HIP, "upload_triples: %s", hipGetErrorString(e));
+    }
     HIPCHK(hipStreamSynchronize(m->stream));
     m->N = N;
     return TFR_OK;
 }
 
+int tfr_upload_triples(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t N) {
+    MODEL_ENTER(m);
+    if (N < 1 || !u || !i || !r) return fail(TFR_ERR_ARG, "upload_triples: need n >= 1 and non-null columns");
+    return build_store(m, u, i, r, N, false);
+}
+
 int tfr_set_triples_dev(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t N) {
     MODEL_ENTER(m);
     if (N < 1 || !du || !di || !dr) return fail(TFR_ERR_ARG, "set_triples_dev: need n >= 1 and non-null columns");
-    HIPCHK(hipStreamSynchronize(m->stream));
-    if (m->store_owned) { dfree(m->su); dfree(m->si); dfree(m->sr); }
-    m->store_owned = false;
-    m->su = const_cast<int32_t*>(du);
-    m->si = const_cast<int32_t*>(di);
-    m->sr = const_cast<float*>(dr);
-    m->N = N;
-    return TFR_OK;
+    return build_store(m, du, di, dr, N, true);
 }
 
 int tfr_init_tables(tfr_model* m, uint64_t seed, float fstd, float bstd) {
@@ -836,7 +890,7 @@ int tfr_stage_ids(tfr_model* m, const int64_t* ids, int64_t n) {
 static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t B) {
     GatherArgs g;
     g.ids = d_ids; g.lo = lo; g.B = B; g.N = m->N;
-    g.su = m->su; g.si = m->si; g.sr = m->sr;
+    g.store = m->store;
     g.u = m->d_u; g.it = m->d_i; g.r = m->d_r; g.err = m->d_err;
     {
         Prof p(m, TFR_K_GATHER);
@@ -970,7 +1024,7 @@ int tfr_shard_forward_reduce(tfr_model* m, const int32_t* du, const int32_t* dsl
         f.u = du; f.it = dslot; f.r = dr; f.logits = d_logits; f.g = m->d_g; f.partials = m->partials; f.err = m->d_err;
         f.B = B; f.U = m->U; f.I = nI;
         f.D = m->D; f.loss = o.loss; f.item_abs = o.item_abs; f.reg_bias = o.reg_bias;
-        nblk = forward_grid(B, m->G);
+        nblk = forward_grid(B, m->G, MODE_TRAIN);
         {
             Prof p(m, TFR_K_FORWARD);
             launch_forward(f, MODE_TRAIN, m->G, m->VEC, nblk, s);
@@ -978,8 +1032,11 @@ int tfr_shard_forward_reduce(tfr_model* m, const int32_t* du, const int32_t* dsl
         HIPCHK(hipGetLastError());
         {
             Prof p(m, TFR_K_SORT);
-            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, dslot, m->ks_i, m->iota, m->ps_i, B, bits_for_rows(nI), s));
-            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, du, m->ks_u, m->iota, m->ps_u, B, m->bits_u, s));
+            const int32_t* keys[2] = {du, dslot};
+            const int bits[2] = {m->bits_u, bits_for_rows(nI)};
+            int32_t* ks[2] = {m->ks_u, m->ks_i};
+            int32_t* ps[2] = {m->ps_u, m->ps_i};
+            if ((rc = radix_sort_columns(m, 2, keys, bits, ks, ps, B))) return rc;
         }
         RedArgs r;
         memset(&r, 0, sizeof(r));
@@ -1077,7 +1134,12 @@ int tfr_shard_apply_items(tfr_model* m, const int32_t* d_item_local, const float
     if (n > 0) {
         {
             Prof p(m, TFR_K_SORT);
-            HIPCHK(sort_pairs(m->sort_tmp, m->sort_tmp_bytes, d_item_local, m->ks_i, m->iota, m->ps_i, n, m->bits_i, s));
+            const int32_t* keys[2] = {d_item_local, nullptr};
+            const int bits[2] = {m->bits_i, 0};
+            int32_t* ks[2] = {m->ks_i, nullptr};
+            int32_t* ps[2] = {m->ps_i, nullptr};
+            // column 0 of the helper uses the "user" scratch; results still land in ks_i / ps_i
+            if ((rc = radix_sort_columns(m, 1, keys, bits, ks, ps, n))) return rc;
         }
         RedPair pr;
         RedArgs& r = pr.a[0];

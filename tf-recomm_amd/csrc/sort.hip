@@ -6,10 +6,10 @@
 //   csort  - hand-written one-pass counting sort for small tables (every row id is its own
 //            bin, all bins in LDS): 3 launches sort BOTH id columns.  This is the
 //            MovieLens-scale path, where launch count, not bytes, bounds the step.
-//   radix  - rocPRIM's LSD radix sort for big tables (only the low `end_bit` bits).
+//   rsort  - hand-written LSD radix sort (8-bit digits) for big tables: 3 launches per pass,
+//            ceil(bits/8) passes, both columns per launch.
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "svd_kernels.h"
 #include "finalize.inc.h"
 
@@ -154,24 +154,99 @@ void launch_csort(const CSortArgs& a, const FinArgs* fin, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
-size_t sort_temp_bytes(int64_t n, int end_bit) {
-    size_t bytes = 0;
-    const unsigned int* kin = nullptr;
-    unsigned int* kout = nullptr;
-    const int32_t* vin = nullptr;
-    int32_t* vout = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u,
-                                             (unsigned)end_bit, (hipStream_t)0);
-    if (e != hipSuccess) return 0;
-    return bytes ? bytes : 16;
+// rsort: LSD radix sort, 8-bit digits, for tables too big for csort.  One pass = three launches
+// (rank / scan / scatter) that handle up to two key columns at once (blockIdx.y).  Each pass is
+// the csort idea with 256 bins: stable tile-local ranks by ballots + ordered wave turns, a
+// bin-major histogram [256][ntiles], a flat exclusive scan of it, and a scatter of (key, value).
+// Stable passes from the least significant digit up give a stable sort.
+__global__ __launch_bounds__(CSORT_TILE) void k_rsort_rank(RSortArgs a) {
+    __shared__ int32_t cnt[256];
+    const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (tid < 256) cnt[tid] = 0;
+    __syncthreads();
+    const int64_t k = (int64_t)tile * CSORT_TILE + tid;
+    const bool valid = k < a.B;
+    const int32_t digit = valid ? ((a.keys_in[col][k] >> a.shift) & 255) : 0;
+    unsigned long long mask = __ballot(valid);
+#pragma unroll
+    for (int bit = 1; bit < 256; bit <<= 1) {
+        const unsigned long long m = __ballot((digit & bit) != 0);
+        mask &= (digit & bit) ? m : ~m;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    const int rank_in_wave = __popcll(below);
+    const int group_size = __popcll(mask);
+    int base = 0;
+    for (int w = 0; w < CSORT_TILE / 64; ++w) {
+        if (wave == w && valid) {
+            base = cnt[digit];
+            if (below == 0) cnt[digit] = base + group_size;
+        }
+        __syncthreads();
+    }
+    if (valid) a.lrank[col][k] = base + rank_in_wave;
+    if (tid < 256) a.hist[col][(size_t)tid * a.ntiles + tile] = cnt[tid];        // bin-major
 }
 
-hipError_t sort_pairs(void* temp, size_t temp_bytes, const int32_t* keys_in, int32_t* keys_out,
-                      const int32_t* vals_in, int32_t* vals_out, int64_t n, int end_bit,
-                      hipStream_t s) {
-    return rocprim::radix_sort_pairs(temp, temp_bytes, reinterpret_cast<const unsigned int*>(keys_in),
-                                     reinterpret_cast<unsigned int*>(keys_out), vals_in, vals_out,
-                                     (size_t)n, 0u, (unsigned)end_bit, s);
+// exclusive scan of hist[256 * ntiles] -> offs, split over blocks of `chunk` contiguous entries:
+// each block scans its chunk locally (thread t owns chunk/1024 <= 16 consecutive entries, so a
+// wave reads one contiguous span) and publishes its total; the scatter adds the totals of the
+// preceding blocks.
+__global__ __launch_bounds__(1024) void k_rsort_scan(RSortArgs a) {
+    __shared__ int32_t wsum[16];
+    const int col = blockIdx.y, tid = threadIdx.x;
+    const int32_t* __restrict__ h = a.hist[col];
+    int32_t* __restrict__ offs = a.offs[col];
+    const int64_t total = (int64_t)256 * a.ntiles;
+    const int per = a.chunk / 1024;                       // entries per thread, <= 16
+    const int64_t lo = (int64_t)blockIdx.x * a.chunk + (int64_t)tid * per;
+    int32_t v[16];
+    int32_t sum = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        v[e] = (e < per && lo + e < total) ? h[lo + e] : 0;
+        sum += v[e];
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    int32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (e < per && lo + e < total) offs[lo + e] = run;
+        run += v[e];
+    }
+    if (tid == 1023) a.blocktot[col][blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(CSORT_TILE) void k_rsort_scatter(RSortArgs a) {
+    const int col = blockIdx.y, tile = blockIdx.x;
+    const int64_t k = (int64_t)tile * CSORT_TILE + threadIdx.x;
+    if (k >= a.B) return;
+    const int32_t key = a.keys_in[col][k];
+    const int32_t digit = (key >> a.shift) & 255;
+    const int64_t idx = (int64_t)digit * a.ntiles + tile;
+    int32_t base = 0;
+    for (int q = 0; q < (int)(idx / a.chunk); ++q) base += a.blocktot[col][q];
+    const int32_t dst = base + a.offs[col][idx] + a.lrank[col][k];
+    a.keys_out[col][dst] = key;
+    a.vals_out[col][dst] = a.vals_in[col] ? a.vals_in[col][k] : (int32_t)k;
+}
+
+void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s) {
+    const dim3 grid(a.ntiles, ncols);
+    hipLaunchKernelGGL(k_rsort_rank, grid, dim3(CSORT_TILE), 0, s, a);
+    const int64_t total = (int64_t)256 * a.ntiles;
+    hipLaunchKernelGGL(k_rsort_scan, dim3((unsigned)((total + a.chunk - 1) / a.chunk), ncols), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_rsort_scatter, grid, dim3(CSORT_TILE), 0, s, a);
 }
 
 }  // namespace tfr

@@ -17,7 +17,7 @@ struct FwdArgs {
     const int32_t* u; const int32_t* it; const float* r;
     // optional fused gather from the resident store (ids != NULL): u/it/r above are then
     // ignored and the gathered ids are written to u_out / it_out for the backward
-    const int64_t* ids; const int32_t* su; const int32_t* si; const float* sr;
+    const int64_t* ids; const int4* store;
     int32_t* u_out; int32_t* it_out;
     float* logits; float* g; float* partials; int32_t* err;
     int64_t B, U, I, N;
@@ -27,7 +27,7 @@ struct FwdArgs {
 struct GatherArgs {
     const int64_t* ids;          // NULL -> contiguous range starting at lo
     int64_t lo, B, N;
-    const int32_t* su; const int32_t* si; const float* sr;
+    const int4* store;
     int32_t* u; int32_t* it; float* r; int32_t* err;
 };
 
@@ -105,7 +105,7 @@ inline bool geometry(int D, int* G, int* VEC) {
     return true;
 }
 
-int forward_grid(int64_t B, int G);
+int forward_grid(int64_t B, int G, int mode);
 void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s);
 void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s);
 void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipStream_t s);
@@ -113,6 +113,7 @@ void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s)
 void launch_gather(const GatherArgs& a, hipStream_t s);
 void launch_gather_rows(const GatherRowsArgs& a, int G, int VEC, hipStream_t s);
 void launch_iota(int32_t* p, int64_t n, hipStream_t s);
+void launch_pack_triples(const int32_t* u, const int32_t* it, const float* r, void* store, int64_t n, hipStream_t s);
 void launch_finalize(const FinArgs& a, hipStream_t s);
 void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s);
 void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s);
@@ -122,9 +123,15 @@ constexpr int CSORT_TILE = 1024;
 constexpr int CSORT_MAX_BINS = 16384;          // 64 KB of LDS counters
 bool csort_eligible(int64_t B, int bits_u, int bits_i);
 void launch_csort(const CSortArgs& a, const FinArgs* fin, hipStream_t s);   // fin: run K4 in the scan launch
-size_t sort_temp_bytes(int64_t n, int end_bit);
-hipError_t sort_pairs(void* temp, size_t temp_bytes, const int32_t* keys_in, int32_t* keys_out,
-                      const int32_t* vals_in, int32_t* vals_out, int64_t n, int end_bit,
-                      hipStream_t s);
+// LSD radix sort pass (8-bit digit at `shift`) over up to two key columns
+struct RSortArgs {
+    const int32_t* keys_in[2]; const int32_t* vals_in[2];    // vals_in NULL -> the batch position
+    int32_t* keys_out[2]; int32_t* vals_out[2];
+    int32_t* lrank[2]; int32_t* hist[2]; int32_t* offs[2];   // hist/offs: [256 * ntiles], bin-major
+    int32_t* blocktot[2];                                    // per scan block (chunk entries) totals
+    int32_t shift, ntiles, chunk;                            // chunk: multiple of 1024, <= 16384
+    int64_t B;
+};
+void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s);
 
 }  // namespace tfr

@@ -129,9 +129,10 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
-                u_n[j] = a.su[id[j]];
-                it_n[j] = a.si[id[j]];
-                rr_n[j] = a.sr[id[j]];
+                const int4 rec = a.store[id[j]];          // one 16-byte record: {user, item, rate bits, -}
+                u_n[j] = rec.x;
+                it_n[j] = rec.y;
+                rr_n[j] = __int_as_float(rec.z);
             }
         } else {
 #pragma unroll
@@ -229,9 +230,10 @@ __global__ __launch_bounds__(256) void k_gather_triples(GatherArgs a) {
          k += (int64_t)gridDim.x * blockDim.x) {
         int64_t id = a.ids ? a.ids[k] : a.lo + k;
         if ((uint64_t)id >= (uint64_t)a.N) { oob = true; id = 0; }
-        a.u[k] = a.su[id];
-        a.it[k] = a.si[id];
-        a.r[k] = a.sr[id];
+        const int4 rec = a.store[id];
+        a.u[k] = rec.x;
+        a.it[k] = rec.y;
+        a.r[k] = __int_as_float(rec.z);
     }
     if (oob) atomicOr(a.err, 2);
 }
@@ -251,6 +253,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(GatherRowsArgs a) {
         if (gl == 0) a.bias_out[j] = a.bias[id];
     }
     if (oob) atomicOr(a.err, 1);
+}
+
+// columns -> 16-byte records of the resident rating store
+__global__ __launch_bounds__(256) void k_pack_triples(const int32_t* u, const int32_t* it, const float* r,
+                                                     int4* store, int64_t n) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x)
+        store[k] = make_int4(u[k], it[k], __float_as_int(r[k]), 0);
 }
 
 __global__ __launch_bounds__(256) void k_iota(int32_t* p, int64_t n) {
@@ -600,10 +610,11 @@ static void launch_forward_mode(const FwdArgs& a, int G, int VEC, int grid, hipS
 #undef TFR_FWD_CASE
 }
 
-int forward_grid(int64_t B, int G) {
+int forward_grid(int64_t B, int G, int mode) {
     const int64_t per_block = 4 * (64 / G) * 4;         // waves * SPW * UNR
     int64_t nb = (B + per_block - 1) / per_block;
-    if (nb > 8192) nb = 8192;                            // then grid-stride (measured: 8192 >= 2048 cap)
+    const int64_t cap = (mode == MODE_INFER) ? 8192 : 2048;   // TRAIN/EVAL: fewer partials for K4
+    if (nb > cap) nb = cap;                              // then grid-stride
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -692,6 +703,10 @@ void launch_gather_rows(const GatherRowsArgs& a, int G, int VEC, hipStream_t s) 
 
 void launch_gather(const GatherArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_triples, dim3(flat_grid(a.B)), dim3(256), 0, s, a);
+}
+
+void launch_pack_triples(const int32_t* u, const int32_t* it, const float* r, void* store, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_triples, dim3(flat_grid(n)), dim3(256), 0, s, u, it, r, reinterpret_cast<int4*>(store), n);
 }
 
 void launch_iota(int32_t* p, int64_t n, hipStream_t s) {
