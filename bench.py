@@ -194,10 +194,16 @@ def main():
     import tfrecomm_amd as T
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)")
+    if os.environ.get("TFR_SHARE_GPU"):          # rehearsal on a 1-GPU box: every rank on device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("TFR_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     if args.only_north_star:
         print(json.dumps(north_star_forward(local_rank, steps=args.steps, warmup=args.warmup, U=args.ns_users,
@@ -211,16 +217,24 @@ def main():
     U, I, D, B = wl["U"], wl["I"], wl["D"], wl["B"]
     K, W = args.steps, args.warmup
 
+    gen = synth_movielens if args.workload in ("c1", "c2") else synth_uniform
     if world > 1:
-        from tfrecomm_amd import sharded
-        res = sharded.bench_entry(wl, K, W, rank, local_rank, world)
+        # tables every GPU can hold -> data parallel (one gradient all-reduce per step); tables at
+        # the scale sharding is meant for -> row-sharded with all-to-all row exchange
+        small = (U + I) * (D + 1) * 4 <= 256 << 20 and wl["adam_mode"] == "tf1"
+        if small:
+            from tfrecomm_amd import dataparallel
+            train, val = gen(U, I, wl["N"])
+            res = dataparallel.bench_entry(wl, K, W, rank, local_rank, world, train, val)
+        else:
+            from tfrecomm_amd import sharded
+            res = sharded.bench_entry(wl, K, W, rank, local_rank, world)
         if rank == 0:
             print(json.dumps(res), flush=True)
         dist.destroy_process_group()
         return
 
     # ---- data: synthetic store + the reference's id stream --------------------------------
-    gen = synth_movielens if args.workload in ("c1", "c2") else synth_uniform
     train, val = gen(U, I, wl["N"])
     ntrain = len(train[0])
     np.random.seed(13575)                                       # svd_train_val.py:15

@@ -166,6 +166,20 @@ int tfr_shard_apply_items(tfr_model* m, const int32_t* d_item_local, const float
                           const float* d_bias_grad, int64_t n_rows);
 int tfr_shard_finish_step(tfr_model* m, const float* d_scalars4 /* global sums */);
 
+/* ---- data-parallel building blocks (replicated tables, small enough that every GPU holds
+ *      them): each rank reduces ITS batch to dense gradient buffers, the host all-reduces one
+ *      flat buffer (RCCL), every rank applies the same dense update - one `minimize`
+ *      (ops.py:143-149) on the union of the ranks' batches.  Needs dense optimiser semantics
+ *      (Adam tf1, which is what tf.train.AdamOptimizer computes, or SGD).
+ *      d_flat: tfr_dp_flat_size() floats, device memory, zero before the first step:
+ *      [user_features grads | item_features grads | user_bias | item_bias | loss, reg, sum_g, 0].
+ *      d_store_ids != NULL: the batch is gathered from the resident store (ids index it). */
+int64_t tfr_dp_flat_size(tfr_model* m);
+int tfr_dp_local_grads(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate,
+                       int64_t batch, const int64_t* d_store_ids, float* d_flat);
+int tfr_dp_apply(tfr_model* m, float* d_flat);
+int tfr_staged_ids_devptr(tfr_model* m, void** ptr, int64_t* n);
+
 /* ---- index work of the backward, exposed for bit-exact checks: stable sort of batch
  *      positions by row id (what tf.unique + unsorted_segment_sum's batch-order walk reduce
  *      to).  side 0 = user ids, 1 = item ids.  Host pointers; outputs [batch]. */

@@ -65,3 +65,54 @@ def test_two_rank_sharded_step_matches_oracle(kw):
 def test_two_rank_d128_long_runs():
     mp.spawn(_worker, args=(2, _free_port(), dict(optimizer="adam", adam_mode="lazy"), 40, 30, 128, 3000, 2),
              nprocs=2, join=True)
+
+
+# ------------------------------------------------------------------ data parallel (replicated tables)
+def _dp_worker(rank, world, port, kw, U, I, D, B, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfrecomm_amd import dataparallel, _lib as L
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        rs = np.random.RandomState(13)
+        t = rand_tables(rs, U, I, D)
+        ref = make_oracle(U, I, D, t, **kw)
+        be = dataparallel.HipReplica(U, I, D, 0, **kw)
+        be.model.set_tables(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        dp = dataparallel.DataParallelSvd(be)
+        for s in range(steps):
+            u, i = dup_heavy_ids(rs, U, world * B), dup_heavy_ids(rs, I, world * B)
+            r = (rs.rand(world * B) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, world * B).astype(np.float32)
+            sl = slice(rank * B, (rank + 1) * B)
+            scal = dp.train_step(torch.from_numpy(u[sl]).to(dev), torch.from_numpy(i[sl]).to(dev), torch.from_numpy(r[sl]).to(dev))
+            _, wloss, wreg = ref.train_step(u, i, r)                    # ONE step on the global batch
+            sc = scal.cpu().numpy()
+            tol = RTOL * (s + 1)
+            assert abs(sc[0] - wloss) <= tol * abs(wloss) and abs(sc[1] - wreg) <= tol * abs(wreg)
+        be.sync()
+        got = be.model.tables()
+        for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+            assert rel_err(got[tid], ref.tables()[tid]) <= RTOL * steps, "table %d" % tid
+        # replicas are bit-identical
+        mine = np.concatenate([got[tid].reshape(-1) for tid in (L.MU, L.BU, L.BI, L.P, L.Q)])
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        assert all(np.array_equal(parts[0], p) for p in parts)
+        assert be.model.step == steps and float(be.flat.abs().max()) == 0.0   # buffer left clean
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(optimizer="adam", adam_mode="tf1"),
+                                dict(optimizer="sgd", loss="nll", item_abs=True, reg_bias=True, lr=5e-3, reg=0.01)])
+def test_two_rank_data_parallel_equals_one_global_step(kw):
+    mp.spawn(_dp_worker, args=(2, _free_port(), kw, 300, 200, 64, 1500, 4), nprocs=2, join=True)
+
+
+def test_data_parallel_rejects_lazy_adam():
+    import tfrecomm_amd as T
+    with T.SvdModel(10, 10, 8, optimizer="adam", adam_mode="lazy") as m:
+        with pytest.raises(T.TfrError):
+            m.dp_apply(1)

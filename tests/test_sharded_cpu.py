@@ -86,3 +86,76 @@ def test_shard_ranges_cover_rows_exactly():
             for r, (lo, hi) in enumerate(spans):
                 ids = np.arange(lo, hi)
                 assert np.all(ids // per == r)
+
+
+# ------------------------------------------------------------------ data parallel under gloo
+class OracleReplica(object):
+    """Stand-in for dataparallel.HipReplica (TEST ONLY): dense per-rank gradients from the oracle."""
+
+    def __init__(self, U, I, D, tables, **kw):
+        self.o = make_oracle(U, I, D, tables, **kw)
+        self.U, self.I, self.D = U, I, D
+        self.flat = torch.zeros(U * D + I * D + U + I + 4, dtype=torch.float64)
+
+    def local_grads(self, u=None, i=None, r=None, store_ids_ptr=None, batch=None):
+        o = self.o
+        u, i, r = u.numpy().astype(np.int64), i.numpy().astype(np.int64), r.numpy().astype(np.float64)
+        lg = so.forward(o.P, o.Q, o.bu, o.bi, o.mu, u, i, o.item_abs)
+        g = so.dlogits(lg, r, o.loss)
+        dP, dQ, dbu, dbi, dmu = so.occurrence_grads(o.P, o.Q, o.bu, o.bi, u, i, g, o.reg, o.item_abs, o.reg_bias)
+        gP, gQ, gbu, gbi = np.zeros((self.U, self.D)), np.zeros((self.I, self.D)), np.zeros(self.U), np.zeros(self.I)
+        np.add.at(gP, u, dP); np.add.at(gQ, i, dQ); np.add.at(gbu, u, dbu); np.add.at(gbi, i, dbi)
+        tail = [so.data_loss(lg, r, o.loss), so.regularizer(o.P, o.Q, o.bu, o.bi, u, i, o.reg_bias), dmu, 0.0]
+        self.flat += torch.from_numpy(np.concatenate([gP.ravel(), gQ.ravel(), gbu, gbi, tail]))
+        return self.flat
+
+    def apply(self, flat):
+        o, f = self.o, flat.numpy()
+        a, b = self.U * self.D, self.U * self.D + self.I * self.D
+        grads = {so.PF: f[:a].reshape(self.U, self.D), so.QF: f[a:b].reshape(self.I, self.D),
+                 so.BU: f[b:b + self.U], so.BI: f[b + self.U:b + self.U + self.I]}
+        for tid, var in ((so.PF, o.P), (so.QF, o.Q), (so.BU, o.bu), (so.BI, o.bi)):
+            if o.optimizer == so.SGD:
+                var -= o.lr * grads[tid]
+            else:       # dense TF1 Adam: every row
+                so.adam_sparse_tf1(var, o.slots[tid], np.arange(var.shape[0]), grads[tid].copy(), o.lr, o.b1p, o.b2p,
+                                   o.b1, o.b2, o.eps)
+        dmu = f[-2]
+        if o.optimizer == so.SGD:
+            o.mu -= o.lr * dmu
+        else:
+            so.adam_dense(o.mu, o.slots[so.MU], dmu, o.lr, o.b1p, o.b2p, o.b1, o.b2, o.eps)
+            o.b1p, o.b2p = o.b1p * o.b1, o.b2p * o.b2
+        flat.zero_()
+
+    def sync(self):
+        pass
+
+
+def _dp_worker(rank, world, port, kw, U, I, D, B, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfrecomm_amd import dataparallel
+        rs = np.random.RandomState(5)
+        t = rand_tables(rs, U, I, D)
+        ref = make_oracle(U, I, D, t, **kw)
+        be = OracleReplica(U, I, D, t, **kw)
+        dp = dataparallel.DataParallelSvd(be)
+        for s in range(steps):
+            u, i = dup_heavy_ids(rs, U, world * B), dup_heavy_ids(rs, I, world * B)
+            r = rs.randint(1, 6, world * B).astype(np.float32)
+            sl = slice(rank * B, (rank + 1) * B)
+            scal = dp.train_step(torch.from_numpy(u[sl]), torch.from_numpy(i[sl]), torch.from_numpy(r[sl]))
+            _, wloss, wreg = ref.train_step(u, i, r)
+            assert abs(scal[0].item() - wloss) <= 1e-10 * abs(wloss) and abs(scal[1].item() - wreg) <= 1e-10 * abs(wreg)
+        for tid in (so.MU, so.BU, so.BI, so.PF, so.QF):
+            assert np.allclose(be.o.tables()[tid], ref.tables()[tid], rtol=1e-10, atol=1e-12)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(optimizer="adam", adam_mode="tf1"), dict(optimizer="sgd", lr=1e-2, reg=0.02)])
+def test_data_parallel_equals_one_global_step(kw):
+    mp.spawn(_dp_worker, args=(2, _free_port(), kw, 40, 30, 5, 64, 3), nprocs=2, join=True)

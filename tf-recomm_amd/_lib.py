@@ -78,6 +78,10 @@ SIGNATURES = {
     "tfr_shard_forward_reduce": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _p, C.c_int64, _p, _p, _p, _p]),
     "tfr_shard_apply_items": (C.c_int, [_p, _p, _p, _p, C.c_int64]),
     "tfr_shard_finish_step": (C.c_int, [_p, _p]),
+    "tfr_dp_flat_size": (C.c_int64, [_p]),
+    "tfr_dp_local_grads": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _p]),
+    "tfr_dp_apply": (C.c_int, [_p, _p]),
+    "tfr_staged_ids_devptr": (C.c_int, [_p, C.POINTER(_p), _i64p]),
     "tfr_sort_segments": (C.c_int, [_p, C.c_int32, _i32p, C.c_int64, _i32p, _i32p]),
     "tfr_profile": (C.c_int, [_p, C.c_int32]),
     "tfr_profile_read": (C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), _i64p]),

@@ -1214,4 +1214,140 @@ int tfr_shard_finish_step(tfr_model* m, const float* d_scalars4) {
     return TFR_OK;
 }
 
+// ---- data-parallel building blocks: replicated tables, one all-reduce per step -----------
+// flat gradient buffer layout (floats): [P grads U*D | Q grads I*D | user_bias U | item_bias I |
+// loss, reg, sum_g, 0].  It must be all zeros before the first tfr_dp_local_grads (tfr_dp_apply
+// leaves it zeroed again, so one cudaMemset at allocation is enough).
+int64_t tfr_dp_flat_size(tfr_model* m) {
+    if (!m) return 0;
+    return m->U * m->D + m->I * m->D + m->U + m->I + 4;
+}
+
+int tfr_dp_local_grads(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
+                       const int64_t* d_store_ids, float* d_flat) {
+    MODEL_ENTER(m);
+    if (!d_flat || B < 0) return fail(TFR_ERR_ARG, "dp_local_grads: bad arguments");
+    if (!d_store_ids && B > 0 && (!du || !di || !dr)) return fail(TFR_ERR_ARG, "dp_local_grads: null batch pointers");
+    if (d_store_ids && !m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples first");
+    const tfr_opts& o = m->o;
+    if (o.optimizer == TFR_OPT_ADAM && o.adam_mode != TFR_ADAM_TF1)
+        return fail(TFR_ERR_STATE, "data-parallel steps need dense semantics: Adam tf1 or SGD");
+    int rc;
+    if ((rc = ensure_capacity(m, B > 0 ? B : 1))) return rc;
+    float* gP = d_flat;
+    float* gQ = gP + m->U * m->D;
+    float* gbu = gQ + m->I * m->D;
+    float* gbi = gbu + m->U;
+    float* tail = gbi + m->I;
+    hipStream_t s = m->stream;
+    int nblk = 0;
+    if (B > 0) {
+        if ((rc = run_forward(m, MODE_TRAIN, du, di, dr, B, nullptr, m->d_g, &nblk, d_store_ids))) return rc;
+        if (d_store_ids) { du = m->d_u; di = m->d_i; }
+        if ((rc = sort_columns(m, du, di, B))) return rc;
+        RedArgs r;
+        memset(&r, 0, sizeof(r));
+        r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
+        r.item_abs = o.item_abs; r.reg_bias = o.reg_bias; r.lam = o.reg;
+        RedPair pr;
+        pr.a[0] = r;
+        pr.a[0].side = 1; pr.a[0].ks = m->ks_i; pr.a[0].ps = m->ps_i; pr.a[0].other = du;
+        pr.a[0].own = m->w[TFR_Q]; pr.a[0].partner = m->w[TFR_P]; pr.a[0].own_bias = m->w[TFR_BI];
+        pr.a[0].grad_rows = m->gq; pr.a[0].grad_bias = m->gbq;
+        pr.a[1] = r;
+        pr.a[1].side = 0; pr.a[1].ks = m->ks_u; pr.a[1].ps = m->ps_u; pr.a[1].other = di;
+        pr.a[1].own = m->w[TFR_P]; pr.a[1].partner = m->w[TFR_Q]; pr.a[1].own_bias = m->w[TFR_BU];
+        pr.a[1].grad_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D; pr.a[1].grad_bias = m->gbp;
+        {
+            Prof p(m, TFR_K_REDUCE_ITEM);
+            launch_seg_reduce(pr, 2, RMODE_SCRATCH, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        ApplyPair app;
+        memset(&app, 0, sizeof(app));
+        app.a[0].err = m->d_err; app.a[0].B = B; app.a[0].D = m->D;
+        app.a[0].ks = m->ks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
+        app.a[0].w = gQ; app.a[0].bias_w = gbi;
+        app.a[1] = app.a[0];
+        app.a[1].ks = m->ks_u; app.a[1].grad_rows = pr.a[1].grad_rows; app.a[1].grad_bias = m->gbp;
+        app.a[1].w = gP; app.a[1].bias_w = gbu;
+        {
+            Prof p(m, TFR_K_APPLY);
+            launch_apply_rows(app, 2, 2, m->G, m->VEC, s);      // emit the reduced rows into the dense buffers
+        }
+        HIPCHK(hipGetLastError());
+    }
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.partials = m->partials; f.nblk = nblk; f.scalars = m->scalars; f.out = tail; f.err = m->d_err;
+    f.mu = m->w[TFR_MU];
+    {
+        Prof p(m, TFR_K_FINALIZE);
+        launch_finalize(f, s);
+    }
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
+int tfr_dp_apply(tfr_model* m, float* d_flat) {
+    MODEL_ENTER(m);
+    if (!d_flat) return fail(TFR_ERR_ARG, "dp_apply: null buffer");
+    const tfr_opts& o = m->o;
+    const bool adam = o.optimizer == TFR_OPT_ADAM;
+    if (adam && o.adam_mode != TFR_ADAM_TF1)
+        return fail(TFR_ERR_STATE, "data-parallel steps need dense semantics: Adam tf1 or SGD");
+    const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
+    float* gP = d_flat;
+    float* gQ = gP + m->U * m->D;
+    float* gbu = gQ + m->I * m->D;
+    float* gbi = gbu + m->U;
+    float* tail = gbi + m->I;
+    DensePair dp;
+    memset(&dp, 0, sizeof(dp));
+    DenseArgs d;
+    memset(&d, 0, sizeof(d));
+    d.err = m->d_err; d.D = m->D; d.opt = adam ? 0 : 1;
+    d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps; d.lr = o.lr;
+    dp.a[0] = d;
+    dp.a[0].dense_grad = gP; dp.a[0].dense_gbias = gbu; dp.a[0].rows = m->U;
+    dp.a[0].w = m->w[TFR_P]; dp.a[0].m = m->m[TFR_P]; dp.a[0].v = m->v[TFR_P];
+    dp.a[0].bias_w = m->w[TFR_BU]; dp.a[0].bias_m = m->m[TFR_BU]; dp.a[0].bias_v = m->v[TFR_BU];
+    dp.a[0].frozen_rows = (m->frozen >> TFR_P) & 1; dp.a[0].frozen_bias = (m->frozen >> TFR_BU) & 1;
+    dp.a[1] = d;
+    dp.a[1].dense_grad = gQ; dp.a[1].dense_gbias = gbi; dp.a[1].rows = m->I;
+    dp.a[1].w = m->w[TFR_Q]; dp.a[1].m = m->m[TFR_Q]; dp.a[1].v = m->v[TFR_Q];
+    dp.a[1].bias_w = m->w[TFR_BI]; dp.a[1].bias_m = m->m[TFR_BI]; dp.a[1].bias_v = m->v[TFR_BI];
+    dp.a[1].frozen_rows = (m->frozen >> TFR_Q) & 1; dp.a[1].frozen_bias = (m->frozen >> TFR_BI) & 1;
+    {
+        Prof p(m, TFR_K_APPLY);
+        launch_adam_dense(dp, 2, m->G, m->VEC, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.partials = tail; f.nblk = 1; f.scalars = m->scalars; f.out = nullptr;
+    f.mu = m->w[TFR_MU]; f.mu_m = m->m[TFR_MU]; f.mu_v = m->v[TFR_MU]; f.err = m->d_err;
+    f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
+    f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
+    {
+        Prof p(m, TFR_K_FINALIZE);
+        launch_finalize(f, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(tail, 0, 16, m->stream));              // scalars consumed
+    if (adam) {
+        m->b1p *= o.beta1;
+        m->b2p *= o.beta2;
+    }
+    m->step += 1;
+    return TFR_OK;
+}
+
+int tfr_staged_ids_devptr(tfr_model* m, void** ptr, int64_t* n) {
+    MODEL_ENTER(m);
+    if (ptr) *ptr = m->d_ids;
+    if (n) *n = m->n_ids;
+    return TFR_OK;
+}
+
 }  // extern "C"

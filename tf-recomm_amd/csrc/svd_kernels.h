@@ -63,11 +63,12 @@ struct ApplyPair { ApplyArgs a[2]; };
 
 struct DenseArgs {
     int32_t* map; const int32_t* ks; const float* grad_rows; const float* grad_bias;
+    float* dense_grad; float* dense_gbias;       // data-parallel: dense gradients [rows,D] / [rows]
     float* w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
     const int32_t* err;
     int64_t rows, B;
-    int32_t D, frozen_rows, frozen_bias;
-    float alpha, b1, b2, eps;
+    int32_t D, frozen_rows, frozen_bias, opt;    // opt: 0 Adam, 1 SGD
+    float alpha, b1, b2, eps, lr;
 };
 struct DensePair { DenseArgs a[2]; };
 

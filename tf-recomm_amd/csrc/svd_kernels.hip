@@ -524,21 +524,34 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
     for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / G; row < a.rows;
          row += (int64_t)gridDim.x * GPB) {
-        const int32_t slot = a.map[row];
+        const int32_t slot = a.map ? a.map[row] : 0;
         const size_t roff = (size_t)row * D;
         Frag<VEC> w, mrow, vrow;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
         if (!a.frozen_rows) {                            // independent of the map: issue first
             w = load_frag<VEC>(a.w + roff, d0, D);
-            mrow = load_frag<VEC>(a.m + roff, d0, D);
-            vrow = load_frag<VEC>(a.v + roff, d0, D);
+            if (a.opt == 0) {
+                mrow = load_frag<VEC>(a.m + roff, d0, D);
+                vrow = load_frag<VEC>(a.v + roff, d0, D);
+            }
         }
         float bw = 0.f, mb = 0.f, vb = 0.f;
-        if (gl == 0 && !a.frozen_bias) { bw = a.bias_w[row]; mb = a.bias_m[row]; vb = a.bias_v[row]; }
+        if (gl == 0 && !a.frozen_bias) {
+            bw = a.bias_w[row];
+            if (a.opt == 0) { mb = a.bias_m[row]; vb = a.bias_v[row]; }
+        }
         Frag<VEC> gr;
         float gb = 0.f;
-        if (slot) {
+        if (a.dense_grad) {                              // data-parallel: all-reduced dense gradients
+            gr = load_frag<VEC>(a.dense_grad + roff, d0, D);
+            gb = a.dense_gbias[row];
+            Frag<VEC> z;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) z.v[q] = 0.f;
+            store_frag<VEC>(a.dense_grad + roff, d0, D, z);      // consumed: clean for the next step
+            if (gl == 0) a.dense_gbias[row] = 0.f;
+        } else if (slot) {
             gr = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, a.B, (int64_t)slot - 1, (int32_t)row, d0, D, gb);
             if (gl == 0) a.map[row] = 0;                 // consumed (after the read above)
         } else {
@@ -546,17 +559,26 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
             for (int q = 0; q < VEC; ++q) gr.v[q] = 0.f;
         }
         if (!a.frozen_rows) {
+            if (a.opt == 0) {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], gr.v[q], c);
+                for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], gr.v[q], c);
+                store_frag<VEC>(a.m + roff, d0, D, mrow);
+                store_frag<VEC>(a.v + roff, d0, D, vrow);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * gr.v[q];
+            }
             store_frag<VEC>(a.w + roff, d0, D, w);
-            store_frag<VEC>(a.m + roff, d0, D, mrow);
-            store_frag<VEC>(a.v + roff, d0, D, vrow);
         }
         if (gl == 0 && !a.frozen_bias) {
-            adam_sparse(bw, mb, vb, gb, c);
+            if (a.opt == 0) {
+                adam_sparse(bw, mb, vb, gb, c);
+                a.bias_m[row] = mb;
+                a.bias_v[row] = vb;
+            } else {
+                bw = bw - a.lr * gb;
+            }
             a.bias_w[row] = bw;
-            a.bias_m[row] = mb;
-            a.bias_v[row] = vb;
         }
     }
 }

@@ -196,6 +196,21 @@ class SvdModel:
     def shard_finish_step(self, d_scalars4):
         L.check(self._lib.tfr_shard_finish_step(self._h, d_scalars4))
 
+    # -- data-parallel building blocks ------------------------------------------------
+    def dp_flat_size(self):
+        return int(self._lib.tfr_dp_flat_size(self._h))
+
+    def dp_local_grads(self, d_user, d_item, d_rate, batch, d_store_ids, d_flat):
+        L.check(self._lib.tfr_dp_local_grads(self._h, d_user, d_item, d_rate, batch, d_store_ids, d_flat))
+
+    def dp_apply(self, d_flat):
+        L.check(self._lib.tfr_dp_apply(self._h, d_flat))
+
+    def staged_ids_devptr(self):
+        p, n = L._p(), C.c_int64()
+        L.check(self._lib.tfr_staged_ids_devptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def table_devptr(self, which):
         p, n = L._p(), C.c_int64()
         L.check(self._lib.tfr_table_devptr(self._h, which, C.byref(p), C.byref(n)))

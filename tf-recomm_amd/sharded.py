@@ -281,7 +281,9 @@ def bench_entry(wl, K, W, rank, local_rank, world):
     m.backend.sync()
     torch.cuda.synchronize()
     comm.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if not comm.stage:
+        el = el.to(dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     return dict(metric="training ratings/sec, MovieLens-1M SVD dim=64 @1 GPU (+ val RMSE)", value=K * Bg / elapsed,
