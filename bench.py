@@ -165,12 +165,48 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
                 device_copy_GBps=copy_gbs, frac_of_device_copy=gbs / copy_gbs)
 
 
+def fm_forward_bench(device, steps=50, warmup=5, F=1_000_000, D=64, n=1 << 20, nnz=8):
+    """BASELINE configs[4]: FM pairwise-interaction forward, 1M sparse features, dim=64; synthetic rows of
+    nnz=8 (1 "user" in [0,4e5), 1 "item" in [4e5,6e5), 6 count-valued features elsewhere)."""
+    import tfrecomm_amd as T
+    import torch
+    dev = torch.device("cuda", device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(13575)
+    cols = [torch.randint(0, 400_000, (n, 1), device=dev, generator=g),
+            torch.randint(400_000, 600_000, (n, 1), device=dev, generator=g),
+            torch.randint(600_000, F, (n, nnz - 2), device=dev, generator=g)]
+    indices = torch.cat(cols, 1).to(torch.int32).contiguous()
+    data = torch.cat([torch.ones(n, 2, device=dev), torch.randint(1, 4, (n, nnz - 2), device=dev, generator=g).float()], 1).contiguous()
+    indptr = (torch.arange(n + 1, device=dev, dtype=torch.int64) * nnz).contiguous()
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    m = T.FmModel(F, D, device=device)
+    m.init(seed=3, stddev=0.1)
+    ms = []
+    for s in range(warmup + steps):
+        m.forward_dev(indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), n, out.data_ptr())
+        t = m.sync()
+        if s >= warmup:
+            ms.append(t)
+    m.close()
+    avg = sum(ms) / len(ms)
+    per_launch = n * (nnz * (4 * D + 12) + 4)
+    gbs = per_launch / (avg * 1e-3) / 1e9
+    return dict(metric="FM second-order forward rows/sec (1M features, dim=64, nnz=8)", value=n / (avg * 1e-3), unit="rows/s",
+                n_gpus=1, steps=steps, warmup=warmup, ms_per_step=avg, higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f32", data="synthetic", config=dict(workload="c5: FM forward F=1M D=64 rows=2^20 nnz=8"),
+                roofline=dict(kernel="k_fm_forward<16,4>", bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=gbs / HBM_PEAK_GBS, traffic=None, algorithmic_bytes_per_launch=per_launch,
+                              avg_launch_us=avg * 1e3), cpu_baseline=None, checksum=float(out.double().sum().item()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=900)
     ap.add_argument("--warmup", type=int, default=90)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5"])
     ap.add_argument("--adam-mode", default=None, choices=["tf1", "lazy"])
     ap.add_argument("--store-ratings", type=int, default=None, help="override the size of the rating store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,6 +241,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.workload == "c5":
+        print(json.dumps(fm_forward_bench(local_rank, steps=min(args.steps, 100), warmup=min(args.warmup, 10))), flush=True)
+        return
     if args.only_north_star:
         print(json.dumps(north_star_forward(local_rank, steps=args.steps, warmup=args.warmup, U=args.ns_users,
                                             I=args.ns_items, B=args.ns_batch, D=args.ns_dim, sequential=args.ns_sequential)), flush=True)

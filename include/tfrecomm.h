@@ -186,6 +186,23 @@ int tfr_staged_ids_devptr(tfr_model* m, void** ptr, int64_t* n);
 int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t batch,
                       int32_t* sorted_ids_out, int32_t* sorted_pos_out);
 
+/* ---- FM second-order forward on CSR rows (BASELINE config 5): forward.py:21-22
+ *      y(x) = mu + x.W + 0.5 * (||x V||^2 - sum_j x_j^2 ||V_j||^2); design matrix fm.py:61-93.
+ *      In the reference the model (mu, W, V) comes from the external libFM binary
+ *      (fm.py:154-155, fm_mangaki.py:39-45); here it is uploaded or initialised on the device.
+ *      CSR uses scipy.sparse's layout: indptr int64 [n_rows+1], indices int32, data f32. */
+typedef struct tfr_fm tfr_fm;
+int tfr_fm_create(tfr_fm** out, int64_t n_features, int32_t dim, int32_t device);
+int tfr_fm_destroy(tfr_fm* m);
+int tfr_fm_set(tfr_fm* m, float mu, const float* W, const float* V);          /* host pointers */
+int tfr_fm_init(tfr_fm* m, uint64_t seed, float stddev);                       /* random W, V on device */
+int tfr_fm_forward(tfr_fm* m, const int64_t* indptr, const int32_t* indices, const float* data,
+                   int64_t n_rows, float* out);                                /* host CSR, synchronous */
+int tfr_fm_forward_dev(tfr_fm* m, const int64_t* d_indptr, const int32_t* d_indices,
+                       const float* d_data, int64_t n_rows, float* d_out);     /* device CSR, async */
+int tfr_fm_sync(tfr_fm* m, float* last_kernel_ms);
+const char* tfr_fm_last_error(void);
+
 /* ---- per-kernel timing with HIP events on the model's stream (bench.py roofline) -------- */
 enum {
     TFR_K_FORWARD = 0,        /* gather-dot forward (+ fused loss/grad when training)       */

@@ -9,5 +9,6 @@ from . import _lib
 from ._lib import TfrError, OutOfRangeError
 from .engine import SvdModel
 from . import dataio, graph, ops, config
+from .fm import FmModel
 
-__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config"]
+__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config", "FmModel"]
