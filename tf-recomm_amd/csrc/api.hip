@@ -192,8 +192,8 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
         if ((rc = dmalloc(&m->offs_i, hi > 256 * ntiles ? hi : 256 * ntiles))) return rc;
         if ((rc = dmalloc(&m->binbase_u, small ? (size_t)1 << m->bits_u : 1))) return rc;
         if ((rc = dmalloc(&m->binbase_i, small ? (size_t)1 << m->bits_i : 1))) return rc;
-        if ((rc = dmalloc(&m->blocktot_u, 64 + 256 * ntiles / 16384))) return rc;
-        if ((rc = dmalloc(&m->blocktot_i, 64 + 256 * ntiles / 16384))) return rc;
+        if ((rc = dmalloc(&m->blocktot_u, 64 + 256 * ntiles / 4096))) return rc;
+        if ((rc = dmalloc(&m->blocktot_i, 64 + 256 * ntiles / 4096))) return rc;
         m->csort_ok = small;
     }
     launch_iota(m->iota, cap, m->stream);
@@ -521,7 +521,7 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
     r.hist[0] = m->hist_u; r.hist[1] = m->hist_i;
     r.offs[0] = m->offs_u; r.offs[1] = m->offs_i;
     r.blocktot[0] = m->blocktot_u; r.blocktot[1] = m->blocktot_i;
-    r.chunk = 16384;                                     // 256*ntiles/16384 scan blocks (<= cap/64K + 1)
+    r.chunk = 4096;                                      // entries per scan block (k_rsort_scan)
     for (int p = 0; p < passes; ++p) {
         const bool to_final = ((passes - 1 - p) % 2) == 0;      // last pass lands in ks_out / ps_out
         for (int c = 0; c < ncols; ++c) {
@@ -565,6 +565,8 @@ static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int6
     return radix_sort_columns(m, 2, keys, bits, ks, ps, B);
 }
 
+static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t B);
+
 // one minibatch on device-resident (u, i, r) - or, with d_store_ids, on rows of the resident
 // store gathered inside the forward kernel; out3 = optional device {loss, reg, sum_g} slot
 static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
@@ -584,7 +586,15 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
     f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
     if (B > 0) {
-        int rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk, d_store_ids);
+        int rc;
+        if (d_store_ids && B >= 32768) {
+            // big batches are bandwidth-bound: a separate gather keeps the forward's dependent chain
+            // at ids -> rows; small batches are launch-bound and gather inside the forward instead
+            if ((rc = gather_batch(m, d_store_ids, 0, B))) return rc;
+            d_store_ids = nullptr;
+            du = m->d_u; di = m->d_i; dr = m->d_r;
+        }
+        rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk, d_store_ids);
         if (rc) return rc;
         if (d_store_ids) { du = m->d_u; di = m->d_i; }
         f.nblk = nblk;

@@ -189,25 +189,19 @@ __global__ __launch_bounds__(CSORT_TILE) void k_rsort_rank(RSortArgs a) {
     if (tid < 256) a.hist[col][(size_t)tid * a.ntiles + tile] = cnt[tid];        // bin-major
 }
 
-// exclusive scan of hist[256 * ntiles] -> offs, split over blocks of `chunk` contiguous entries:
-// each block scans its chunk locally (thread t owns chunk/1024 <= 16 consecutive entries, so a
-// wave reads one contiguous span) and publishes its total; the scatter adds the totals of the
-// preceding blocks.
+// exclusive scan of hist[256 * ntiles] -> offs, split over blocks of 4096 contiguous entries:
+// each block scans its chunk locally (one coalesced int4 per thread) and publishes its total; the
+// scatter adds the totals of the preceding blocks.
 __global__ __launch_bounds__(1024) void k_rsort_scan(RSortArgs a) {
     __shared__ int32_t wsum[16];
     const int col = blockIdx.y, tid = threadIdx.x;
     const int32_t* __restrict__ h = a.hist[col];
     int32_t* __restrict__ offs = a.offs[col];
-    const int64_t total = (int64_t)256 * a.ntiles;
-    const int per = a.chunk / 1024;                       // entries per thread, <= 16
-    const int64_t lo = (int64_t)blockIdx.x * a.chunk + (int64_t)tid * per;
-    int32_t v[16];
-    int32_t sum = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        v[e] = (e < per && lo + e < total) ? h[lo + e] : 0;
-        sum += v[e];
-    }
+    const int64_t total = (int64_t)256 * a.ntiles;        // a multiple of 256
+    const int64_t lo = (int64_t)blockIdx.x * 4096 + (int64_t)tid * 4;      // chunk = 4096: one int4 per thread
+    int4 v = make_int4(0, 0, 0, 0);
+    if (lo < total) v = *reinterpret_cast<const int4*>(h + lo);
+    const int32_t sum = (v.x + v.y) + (v.z + v.w);
     const int lane = tid & 63, wave = tid >> 6;
     int32_t incl = sum;
 #pragma unroll
@@ -219,12 +213,8 @@ __global__ __launch_bounds__(1024) void k_rsort_scan(RSortArgs a) {
     __syncthreads();
     int32_t run = incl - sum;
     for (int w = 0; w < wave; ++w) run += wsum[w];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        if (e < per && lo + e < total) offs[lo + e] = run;
-        run += v[e];
-    }
-    if (tid == 1023) a.blocktot[col][blockIdx.x] = run;
+    if (lo < total) *reinterpret_cast<int4*>(offs + lo) = make_int4(run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z);
+    if (tid == 1023) a.blocktot[col][blockIdx.x] = run + sum;
 }
 
 __global__ __launch_bounds__(CSORT_TILE) void k_rsort_scatter(RSortArgs a) {

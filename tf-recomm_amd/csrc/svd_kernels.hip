@@ -95,10 +95,9 @@ __device__ __forceinline__ void block_sum_store(float (&val)[NV], float* out) {
 //                 (svd_train_val.py:144-149)
 // A lane group owns one rating at a time; UNR ratings are in flight per group so each
 // lane has 2*UNR independent 16-byte loads outstanding.
-template <int G, int VEC, int MODE>
+template <int G, int VEC, int MODE, int UNR>
 __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
-    constexpr int SPW = 64 / G;        // ratings per wave per pass
-    constexpr int UNR = 4;             // passes in flight
+    constexpr int SPW = 64 / G;        // ratings per wave per pass; UNR passes in flight
     constexpr int SPI = SPW * UNR;     // ratings per wave-iteration
     const int lane = threadIdx.x & 63;
     const int sub = lane / G;
@@ -623,17 +622,17 @@ __global__ void k_init_uniform_scalar(float* p, float lo, float hi, uint64_t see
 
 // ------------------------------------------------------------------------------------
 // launch helpers
-template <int MODE>
+template <int MODE, int UNR>
 static void launch_forward_mode(const FwdArgs& a, int G, int VEC, int grid, hipStream_t s) {
 #define TFR_FWD_CASE(g, v) \
-    if (G == g && VEC == v) { hipLaunchKernelGGL((k_forward<g, v, MODE>), dim3(grid), dim3(256), 0, s, a); return; }
+    if (G == g && VEC == v) { hipLaunchKernelGGL((k_forward<g, v, MODE, UNR>), dim3(grid), dim3(256), 0, s, a); return; }
     TFR_FWD_CASE(4, 4) TFR_FWD_CASE(8, 4) TFR_FWD_CASE(16, 4) TFR_FWD_CASE(32, 4) TFR_FWD_CASE(64, 4)
     TFR_FWD_CASE(4, 1) TFR_FWD_CASE(8, 1) TFR_FWD_CASE(16, 1) TFR_FWD_CASE(32, 1) TFR_FWD_CASE(64, 1)
 #undef TFR_FWD_CASE
 }
 
 int forward_grid(int64_t B, int G, int mode) {
-    const int64_t per_block = 4 * (64 / G) * 4;         // waves * SPW * UNR
+    const int64_t per_block = 4 * (64 / G) * 4;   // waves * SPW * UNR
     int64_t nb = (B + per_block - 1) / per_block;
     const int64_t cap = (mode == MODE_INFER) ? 8192 : 2048;   // TRAIN/EVAL: fewer partials for K4
     if (nb > cap) nb = cap;                              // then grid-stride
@@ -642,9 +641,9 @@ int forward_grid(int64_t B, int G, int mode) {
 }
 
 void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s) {
-    if (mode == MODE_INFER) launch_forward_mode<MODE_INFER>(a, G, VEC, grid, s);
-    else if (mode == MODE_TRAIN) launch_forward_mode<MODE_TRAIN>(a, G, VEC, grid, s);
-    else launch_forward_mode<MODE_EVAL>(a, G, VEC, grid, s);
+    if (mode == MODE_INFER) launch_forward_mode<MODE_INFER, 4>(a, G, VEC, grid, s);
+    else if (mode == MODE_TRAIN) launch_forward_mode<MODE_TRAIN, 4>(a, G, VEC, grid, s);
+    else launch_forward_mode<MODE_EVAL, 4>(a, G, VEC, grid, s);
 }
 
 static int entry_grid(int64_t B, int G) {
