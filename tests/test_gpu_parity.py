@@ -380,3 +380,48 @@ def test_forward_large_properties():
     sel = rs.randint(0, B, 4096)
     want = (P[u[sel]].astype(np.float64) * Q[i[sel]]).sum(1) + 0.25 + bu[u[sel]] + bi[i[sel]]
     assert_close(a[sel], want, what="sampled logits")
+
+
+# ------------------------------------------------------------------ randomized sweep
+def _sweep_cases():
+    rs = np.random.RandomState(2024)
+    dims = [1, 2, 3, 4, 7, 12, 16, 24, 33, 48, 60, 64, 100, 128, 200, 252, 256]
+    cases = []
+    for n in range(24):
+        D = dims[rs.randint(len(dims))]
+        U, I = int(rs.randint(1, 3000)), int(rs.randint(1, 2000))
+        B = int(rs.choice([1, 2, 31, 64, 100, 777, 1024, 1025, 4097, 20000]))
+        opt, mode = [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")][rs.randint(3)]
+        loss = ["mse", "nll"][rs.randint(2)]
+        cases.append((n, U, I, D, B, opt, mode, loss, bool(rs.randint(2)), bool(rs.randint(2))))
+    # both sort paths with small tables: B big enough that the counting sort's table would not fit
+    cases.append((100, 6040, 3952, 64, 300000, "adam", "tf1", "mse", False, False))
+    cases.append((101, 20000, 17000, 32, 5000, "adam", "lazy", "mse", False, False))     # > 16384 rows: radix
+    cases.append((102, 3, 2, 64, 9000, "adam", "lazy", "nll", True, True))               # very long runs
+    return cases
+
+
+@pytest.mark.parametrize("case", _sweep_cases(), ids=lambda c: "n%d_U%d_I%d_D%d_B%d_%s_%s_%s" % c[:8])
+def test_random_shapes_two_steps(case):
+    n, U, I, D, B, opt, mode, loss, item_abs, reg_bias = case
+    rs = np.random.RandomState(1000 + n)
+    t = rand_tables(rs, U, I, D, scale=0.3 / np.sqrt(max(D, 16) / 16))
+    kw = dict(loss=loss, item_abs=item_abs, reg_bias=reg_bias, optimizer=opt, adam_mode=mode, lr=3e-3, reg=0.02)
+    orc = make_oracle(U, I, D, t, **kw)
+    with model_from(U, I, D, t, **kw) as m:
+        for s in range(2):
+            u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+            r = (rs.rand(B) < 0.5).astype(np.float32) if loss == "nll" else rs.randint(1, 6, B).astype(np.float32)
+            logits, lossv, regv = m.train_step(u, i, r)
+            wl, wloss, wreg = orc.train_step(u, i, r)
+            tol = 2 * RTOL * (s + 1)
+            assert_close(logits, wl, rtol=tol, what="logits")
+            assert_close(lossv, wloss, rtol=tol, what="loss")
+            assert_close(regv, wreg, rtol=tol, what="reg")
+        got = m.tables()
+        for tid in TIDS:
+            # dup_heavy_ids puts 70 % of the batch on 10 % of the rows: a hot row's gradient is an fp32
+            # sum of ~7*B/rows terms; rounding error grows ~sqrt(terms) (loss/logits above stay 1e-5)
+            run = 7.0 * B / max(1, min(U, I))
+            assert_close(got[tid], orc.tables()[tid], rtol=4 * RTOL * max(1.0, np.sqrt(run / 64)),
+                         what="table %s" % TABLE_NAMES[tid])
