@@ -594,11 +594,50 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             d_store_ids = nullptr;
             du = m->d_u; di = m->d_i; dr = m->d_r;
         }
-        rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk, d_store_ids);
-        if (rc) return rc;
-        if (d_store_ids) { du = m->d_u; di = m->d_i; }
-        f.nblk = nblk;
-        if ((rc = sort_columns(m, du, di, B, &f, &fin_done))) return rc;
+        if (m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i)) {
+            // small tables: forward and the counting sort's rank pass share one launch, then
+            // scan (+K4) and scatter
+            FrontArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            FwdArgs& fw = fa.f;
+            fw.P = m->w[TFR_P]; fw.Q = m->w[TFR_Q]; fw.bu = m->w[TFR_BU]; fw.bi = m->w[TFR_BI]; fw.mu = m->w[TFR_MU];
+            fw.u = du; fw.it = di; fw.r = dr;
+            fw.logits = d_logits; fw.g = m->d_g; fw.partials = m->partials; fw.err = m->d_err;
+            fw.B = B; fw.U = m->U; fw.I = m->I; fw.N = m->N;
+            fw.D = m->D; fw.loss = o.loss; fw.item_abs = o.item_abs; fw.reg_bias = o.reg_bias;
+            if (d_store_ids) { fw.ids = d_store_ids; fw.store = m->store; }     // rank blocks publish the ids
+            CSortArgs& c = fa.c;
+            c.keys[0] = d_store_ids ? m->d_u : du; c.keys[1] = d_store_ids ? m->d_i : di;
+            c.ks[0] = m->ks_u; c.ks[1] = m->ks_i; c.ps[0] = m->ps_u; c.ps[1] = m->ps_i;
+            c.lrank[0] = m->lrank_u; c.lrank[1] = m->lrank_i; c.hist[0] = m->hist_u; c.hist[1] = m->hist_i;
+            c.offs[0] = m->offs_u; c.offs[1] = m->offs_i; c.binbase[0] = m->binbase_u; c.binbase[1] = m->binbase_i;
+            c.blocktot[0] = m->blocktot_u; c.blocktot[1] = m->blocktot_i;
+            c.nbins[0] = 1 << m->bits_u; c.nbins[1] = 1 << m->bits_i;
+            c.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+            c.B = B;
+            fa.key_out[0] = m->d_u; fa.key_out[1] = m->d_i;
+            fa.nfwd = front_forward_blocks(B, m->G);
+            nblk = fa.nfwd;
+            {
+                Prof p(m, TFR_K_FORWARD);
+                launch_front(fa, m->G, m->VEC, s);
+            }
+            HIPCHK(hipGetLastError());
+            if (d_store_ids) { du = m->d_u; di = m->d_i; }
+            f.nblk = nblk;
+            {
+                Prof p(m, TFR_K_SORT);
+                launch_csort_tail(c, &f, s);
+            }
+            HIPCHK(hipGetLastError());
+            fin_done = true;
+        } else {
+            rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk, d_store_ids);
+            if (rc) return rc;
+            if (d_store_ids) { du = m->d_u; di = m->d_i; }
+            f.nblk = nblk;
+            if ((rc = sort_columns(m, du, di, B, &f, &fin_done))) return rc;
+        }
         RedArgs r;
         memset(&r, 0, sizeof(r));
         r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;

@@ -153,6 +153,16 @@ void launch_csort(const CSortArgs& a, const FinArgs* fin, hipStream_t s) {
     hipLaunchKernelGGL(k_csort_scatter, grid, dim3(CSORT_TILE), 0, s, a);
 }
 
+// scan (+ optional K4) and scatter only: the rank pass already ran inside k_front
+void launch_csort_tail(const CSortArgs& a, const FinArgs* fin, hipStream_t s) {
+    const int nbmax = a.nbins[0] > a.nbins[1] ? a.nbins[0] : a.nbins[1];
+    ScanFinArgs sa;
+    sa.c = a;
+    if (fin) sa.f = *fin; else memset(&sa.f, 0, sizeof(sa.f));
+    hipLaunchKernelGGL(k_csort_scan, dim3((nbmax + 1023) / 1024, fin ? 3 : 2), dim3(1024), 0, s, sa);
+    hipLaunchKernelGGL(k_csort_scatter, dim3(a.ntiles, 2), dim3(CSORT_TILE), 0, s, a);
+}
+
 // ------------------------------------------------------------------------------------
 // rsort: LSD radix sort, 8-bit digits, for tables too big for csort.  One pass = three launches
 // (rank / scan / scatter) that handle up to two key columns at once (blockIdx.y).  Each pass is

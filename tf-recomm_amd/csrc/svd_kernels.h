@@ -94,6 +94,13 @@ struct CSortArgs {
     int64_t B;
 };
 
+// forward + csort rank pass in one launch (small tables)
+struct FrontArgs {
+    FwdArgs f; CSortArgs c;
+    int32_t* key_out[2];         // fused-gather mode: where the rank blocks publish the gathered ids
+    int32_t nfwd;                // number of forward blocks (1024 threads each)
+};
+
 // row geometry for a dim: returns false if unsupported
 inline bool geometry(int D, int* G, int* VEC) {
     if (D < 1) return false;
@@ -108,6 +115,9 @@ inline bool geometry(int D, int* G, int* VEC) {
 
 int forward_grid(int64_t B, int G, int mode);
 void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s);
+int front_forward_blocks(int64_t B, int G);
+void launch_front(const FrontArgs& fa, int G, int VEC, hipStream_t s);
+void launch_csort_tail(const CSortArgs& a, const FinArgs* fin, hipStream_t s);   // scan (+K4) and scatter only
 void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s);
 void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipStream_t s);
 void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s);

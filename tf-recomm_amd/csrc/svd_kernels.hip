@@ -69,10 +69,10 @@ __device__ __forceinline__ float wave_sum(float x) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// block-level sum of NV values per thread -> out[NV] written by thread 0.  256 threads.
-template <int NV>
+// block-level sum of NV values per thread -> out[NV] written by thread 0.  NW waves per block.
+template <int NV, int NW>
 __device__ __forceinline__ void block_sum_store(float (&val)[NV], float* out) {
-    __shared__ float red[4][NV];
+    __shared__ float red[NW][NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
@@ -82,7 +82,12 @@ __device__ __forceinline__ void block_sum_store(float (&val)[NV], float* out) {
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int c = 0; c < NV; ++c) out[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        for (int c = 0; c < NV; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w += 4) t += (red[w][c] + red[w + 1][c]) + (red[w + 2][c] + red[w + 3][c]);
+            out[c] = t;
+        }
     }
 }
 
@@ -95,8 +100,8 @@ __device__ __forceinline__ void block_sum_store(float (&val)[NV], float* out) {
 //                 (svd_train_val.py:144-149)
 // A lane group owns one rating at a time; UNR ratings are in flight per group so each
 // lane has 2*UNR independent 16-byte loads outstanding.
-template <int G, int VEC, int MODE, int UNR>
-__global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
+template <int G, int VEC, int MODE, int UNR, int NW>
+__device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nblocks) {
     constexpr int SPW = 64 / G;        // ratings per wave per pass; UNR passes in flight
     constexpr int SPI = SPW * UNR;     // ratings per wave-iteration
     const int lane = threadIdx.x & 63;
@@ -104,8 +109,8 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
     const int gl = lane % G;
     const int d0 = gl * VEC;
     const int D = a.D;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4 * SPI;
+    const int64_t wave_id = (int64_t)block * NW + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)nblocks * NW * SPI;
     const float mu = *a.mu;
 
     float acc[3] = {0.f, 0.f, 0.f};    // TRAIN: loss, reg, sum g | EVAL: sse, n_equal, -
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
             k[j] = base + j * SPW + sub;
             ok[j] = k[j] < a.B;
             u[j] = u_n[j]; it[j] = it_n[j]; rr[j] = rr_n[j];
-            if (a.ids && gl == 0 && ok[j]) { a.u_out[k[j]] = u[j]; a.it_out[k[j]] = it[j]; }   // kept for the backward
+            if (a.ids && a.u_out && gl == 0 && ok[j]) { a.u_out[k[j]] = u[j]; a.it_out[k[j]] = it[j]; }   // kept for the backward
             if ((uint64_t)(int64_t)u[j] >= (uint64_t)a.U) { oob = true; u[j] = 0; }
             if ((uint64_t)(int64_t)it[j] >= (uint64_t)a.I) { oob = true; it[j] = 0; }
         }
@@ -216,7 +221,65 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
     }
     if (oob) atomicOr(a.err, 1);
     if (oob_store) atomicOr(a.err, 2);
-    if constexpr (MODE != MODE_INFER) block_sum_store<3>(acc, a.partials + (size_t)blockIdx.x * 4);
+    if constexpr (MODE != MODE_INFER) block_sum_store<3, NW>(acc, a.partials + (size_t)block * 4);
+}
+
+template <int G, int VEC, int MODE, int UNR>
+__global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
+    forward_body<G, VEC, MODE, UNR, 4>(a, blockIdx.x, gridDim.x);
+}
+
+// Small-table training: the forward and the counting sort's rank pass do not depend on each other,
+// so they share one launch - blocks [0, nfwd) run the forward (16 waves each), the rest rank one
+// (tile, column) each.  In fused-gather mode the rank blocks read the store records themselves and
+// publish the gathered ids for the later passes.
+template <int G, int VEC>
+__global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
+    if ((int)blockIdx.x < fa.nfwd) {
+        forward_body<G, VEC, MODE_TRAIN, 2, 16>(fa.f, blockIdx.x, fa.nfwd);
+        return;
+    }
+    extern __shared__ int32_t cnt[];
+    const CSortArgs& a = fa.c;
+    const int rb = blockIdx.x - fa.nfwd;
+    const int col = rb / a.ntiles, tile = rb % a.ntiles, tid = threadIdx.x;
+    const int nb = a.nbins[col];
+    for (int b = tid; b < nb; b += CSORT_TILE) cnt[b] = 0;
+    __syncthreads();
+    const int64_t k = (int64_t)tile * CSORT_TILE + tid;
+    const bool valid = k < a.B;
+    int32_t key = 0;
+    if (valid) {
+        if (fa.f.ids) {
+            int64_t id = fa.f.ids[k];
+            if ((uint64_t)id >= (uint64_t)fa.f.N) id = 0;          // flagged by the forward blocks
+            const int4 rec = fa.f.store[id];
+            key = col == 0 ? rec.x : rec.y;
+            fa.key_out[col][k] = key;
+        } else {
+            key = a.keys[col][k];
+        }
+        key &= nb - 1;
+    }
+    unsigned long long mask = __ballot(valid);
+    for (int bit = 1; bit < nb; bit <<= 1) {
+        const unsigned long long m = __ballot((key & bit) != 0);
+        mask &= (key & bit) ? m : ~m;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    const int rank_in_wave = __popcll(below);
+    const int group_size = __popcll(mask);
+    int base = 0;
+    for (int w = 0; w < CSORT_TILE / 64; ++w) {
+        if (wave == w && valid) {
+            base = cnt[key];
+            if (below == 0) cnt[key] = base + group_size;
+        }
+        __syncthreads();
+    }
+    if (valid) a.lrank[col][k] = base + rank_in_wave;
+    for (int b = tid; b < nb; b += CSORT_TILE) a.hist[col][(size_t)tile * nb + b] = cnt[b];
 }
 
 // ------------------------------------------------------------------------------------
@@ -638,6 +701,33 @@ int forward_grid(int64_t B, int G, int mode) {
     if (nb > cap) nb = cap;                              // then grid-stride
     if (nb < 1) nb = 1;
     return (int)nb;
+}
+
+int front_forward_blocks(int64_t B, int G) {
+    const int64_t per_block = 16 * (64 / G) * 2;        // waves * SPW * UNR of k_front's forward part
+    int64_t nb = (B + per_block - 1) / per_block;
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+void launch_front(const FrontArgs& fa, int G, int VEC, hipStream_t s) {
+    const int nbmax = fa.c.nbins[0] > fa.c.nbins[1] ? fa.c.nbins[0] : fa.c.nbins[1];
+    const dim3 grid(fa.nfwd + 2 * fa.c.ntiles);
+#define TFR_FRONT_CASE(g, v)                                                                          \
+    if (G == g && VEC == v) {                                                                         \
+        static bool attr = false;                                                                     \
+        if (!attr) {                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<g, v>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, CSORT_MAX_BINS * 4); \
+            attr = true;                                                                              \
+        }                                                                                             \
+        hipLaunchKernelGGL((k_front<g, v>), grid, dim3(1024), (size_t)nbmax * 4, s, fa);              \
+        return;                                                                                       \
+    }
+    TFR_FRONT_CASE(4, 4) TFR_FRONT_CASE(8, 4) TFR_FRONT_CASE(16, 4) TFR_FRONT_CASE(32, 4) TFR_FRONT_CASE(64, 4)
+    TFR_FRONT_CASE(4, 1) TFR_FRONT_CASE(8, 1) TFR_FRONT_CASE(16, 1) TFR_FRONT_CASE(32, 1) TFR_FRONT_CASE(64, 1)
+#undef TFR_FRONT_CASE
 }
 
 void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s) {
