@@ -63,6 +63,7 @@ struct tfr_model {
     bool csort_ok = false;
     float *gq = nullptr, *gp = nullptr, *gbq = nullptr, *gbp = nullptr;
     int32_t *map_u = nullptr, *map_i = nullptr;
+    float *dg_p = nullptr, *dg_q = nullptr, *dg_bu = nullptr, *dg_bi = nullptr;   // tf1: dense per-row gradients
     float* partials = nullptr;
     float* scalars = nullptr;         // {loss, reg, sum_g, -}
     float* step_out = nullptr;        // per-step {loss, reg, sum_g} ring for multi-step calls
@@ -266,7 +267,7 @@ int tfr_destroy(tfr_model* m) {
     for (auto& e : m->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     free_workspace(m);
     for (int t = 0; t < 5; ++t) { dfree(m->w[t]); dfree(m->m[t]); dfree(m->v[t]); }
-    dfree(m->map_u); dfree(m->map_i); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
+    dfree(m->map_u); dfree(m->map_i); dfree(m->dg_p); dfree(m->dg_q); dfree(m->dg_bu); dfree(m->dg_bi); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
     dfree(m->store);
     dfree(m->d_ids);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
@@ -333,6 +334,20 @@ int tfr_create(tfr_model** out, int64_t U, int64_t I, int32_t D, const tfr_opts*
                 hipMemsetAsync(m->map_i, 0, (size_t)I * 4, m->stream) != hipSuccess) {
                 rc = fail(TFR_ERR_HIP, "memset failed");
                 break;
+            }
+            // dense per-row gradient buffers for the TF1 sweep, while they stay small (<= 256 MB)
+            if ((size_t)(U + I) * (D + 1) * 4 <= ((size_t)256 << 20)) {
+                if ((rc = dmalloc(&m->dg_p, (size_t)U * D))) break;
+                if ((rc = dmalloc(&m->dg_q, (size_t)I * D))) break;
+                if ((rc = dmalloc(&m->dg_bu, (size_t)U))) break;
+                if ((rc = dmalloc(&m->dg_bi, (size_t)I))) break;
+                if (hipMemsetAsync(m->dg_p, 0, (size_t)U * D * 4, m->stream) != hipSuccess ||
+                    hipMemsetAsync(m->dg_q, 0, (size_t)I * D * 4, m->stream) != hipSuccess ||
+                    hipMemsetAsync(m->dg_bu, 0, (size_t)U * 4, m->stream) != hipSuccess ||
+                    hipMemsetAsync(m->dg_bi, 0, (size_t)I * 4, m->stream) != hipSuccess) {
+                    rc = fail(TFR_ERR_HIP, "memset failed");
+                    break;
+                }
             }
         }
         if ((rc = dmalloc(&m->scalars, 4))) break;
@@ -661,6 +676,10 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         if (tf1) {
             // both sides only read the tables: one launch
             ru.grad_rows = m->gp;
+            if (m->dg_p) {
+                ri.dense_rows = m->dg_q; ri.dense_bias = m->dg_bi;
+                ru.dense_rows = m->dg_p; ru.dense_bias = m->dg_bu;
+            }
             RedPair pr;
             pr.a[0] = ri; pr.a[1] = ru;
             Prof p(m, TFR_K_REDUCE_ITEM);
@@ -715,12 +734,14 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         DensePair dp;
         dp.a[0] = d;
         dp.a[0].map = m->map_u; dp.a[0].ks = m->ks_u; dp.a[0].grad_rows = m->gp; dp.a[0].grad_bias = m->gbp;
+        dp.a[0].dense_grad = m->dg_p; dp.a[0].dense_gbias = m->dg_bu;
         dp.a[0].rows = m->U;
         dp.a[0].w = m->w[TFR_P]; dp.a[0].m = m->m[TFR_P]; dp.a[0].v = m->v[TFR_P];
         dp.a[0].bias_w = m->w[TFR_BU]; dp.a[0].bias_m = m->m[TFR_BU]; dp.a[0].bias_v = m->v[TFR_BU];
         dp.a[0].frozen_rows = (m->frozen >> TFR_P) & 1; dp.a[0].frozen_bias = (m->frozen >> TFR_BU) & 1;
         dp.a[1] = d;
         dp.a[1].map = m->map_i; dp.a[1].ks = m->ks_i; dp.a[1].grad_rows = m->gq; dp.a[1].grad_bias = m->gbq;
+        dp.a[1].dense_grad = m->dg_q; dp.a[1].dense_gbias = m->dg_bi;
         dp.a[1].rows = m->I;
         dp.a[1].w = m->w[TFR_Q]; dp.a[1].m = m->m[TFR_Q]; dp.a[1].v = m->v[TFR_Q];
         dp.a[1].bias_w = m->w[TFR_BI]; dp.a[1].bias_m = m->m[TFR_BI]; dp.a[1].bias_v = m->v[TFR_BI];

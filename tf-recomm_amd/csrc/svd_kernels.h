@@ -36,6 +36,7 @@ struct RedArgs {
     const float* own; const float* partner; const float* own_bias;
     float* own_w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
     float* grad_rows; float* grad_bias; int32_t* map;
+    float* dense_rows; float* dense_bias;          // optional dense [rows,D] / [rows] gradient buffers
     const float* rows_in; const float* bias_in;    // sharded owner side: pre-reduced gradient rows
     const int32_t* err;
     int64_t B;

@@ -449,11 +449,16 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     bool cont = false;                                   // does the run continue in the next block?
     if (e == EPB && blk0 + EPB < a.B) cont = (a.ks[blk0 + EPB] == row);
     const bool whole = head && !cont;
-    if (RMODE == RMODE_SCRATCH || !whole) {
+    if (RMODE == RMODE_SCRATCH && whole && a.dense_rows) {
+        // dense-gradient form (TF1 Adam sweep / data parallel): a run that lies in one block goes
+        // straight to its row of the dense buffer - the consumer streams it with no indirection
+        store_frag<VEC>(a.dense_rows + roff, d0, D, acc);
+        if (gl == 0) a.dense_bias[row] = gb;
+    } else if (RMODE == RMODE_SCRATCH || !whole) {
         store_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D, acc);
         if (gl == 0) {
             a.grad_bias[j] = gb;
-            if (head && a.map) a.map[row] = (int32_t)j + 1;
+            if (head && a.map) a.map[row] = (int32_t)j + 1;      // split run: where its pieces start
         }
     } else if constexpr (RMODE == RMODE_ADAM) {
         if (!a.frozen_rows) {
@@ -605,9 +610,13 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
         }
         Frag<VEC> gr;
         float gb = 0.f;
-        if (a.dense_grad) {                              // data-parallel: all-reduced dense gradients
+        if (a.dense_grad) {                              // dense gradients (whole runs land here directly)
             gr = load_frag<VEC>(a.dense_grad + roff, d0, D);
             gb = a.dense_gbias[row];
+            if (slot) {                                  // a run split over several reduce blocks
+                gr = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, a.B, (int64_t)slot - 1, (int32_t)row, d0, D, gb);
+                if (gl == 0) a.map[row] = 0;
+            }
             Frag<VEC> z;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) z.v[q] = 0.f;
