@@ -440,11 +440,31 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     Frag<VEC> acc = t;
     float gb = tb;
     int e = grp + 1;
-    while (e < EPB && lds_key[e] == row) {
+    for (;;) {                                           // four LDS entries per round trip, added in order
+        bool same[4];
+        float xv[4][VEC], xb[4];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) acc.v[q] += lds_t[(e * G + gl) * VEC + q];
-        gb += lds_gb[e];
-        ++e;
+        for (int q = 0; q < 4; ++q) {
+            const int ee = (e + q < EPB) ? e + q : grp;   // in-bounds address; masked by same[]
+            same[q] = (e + q < EPB) && (lds_key[ee] == row);
+#pragma unroll
+            for (int c2 = 0; c2 < VEC; ++c2) xv[q][c2] = lds_t[(ee * G + gl) * VEC + c2];
+            xb[q] = lds_gb[ee];
+        }
+        bool go = true;
+        int taken = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            go = go && same[q];
+            if (go) {
+#pragma unroll
+                for (int c2 = 0; c2 < VEC; ++c2) acc.v[c2] += xv[q][c2];
+                gb += xb[q];
+                ++taken;
+            }
+        }
+        e += taken;
+        if (!go) break;
     }
     bool cont = false;                                   // does the run continue in the next block?
     if (e == EPB && blk0 + EPB < a.B) cont = (a.ks[blk0 + EPB] == row);
@@ -488,7 +508,9 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 }
 
 // a run's reduced gradient = its pieces added in piece order (head piece first); pieces
-// start at the run head and at every multiple of PIECE (= the reduce kernel's block span)
+// start at the run head and at every multiple of PIECE (= the reduce kernel's block span).
+// Continuation pieces are probed and loaded eight at a time (independent loads), so a hot row
+// split into a handful of pieces costs two memory round trips, not one per piece.
 template <int VEC, int PIECE>
 __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_rows,
                                                const float* __restrict__ grad_bias,
@@ -496,11 +518,35 @@ __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_ro
                                                int32_t row, int d0, int D, float& gb) {
     Frag<VEC> t = load_frag<VEC>(grad_rows + (size_t)j * D, d0, D);
     gb = grad_bias[j];
-    for (int64_t p = (j / PIECE + 1) * PIECE; p < B && ks[p] == row; p += PIECE) {
-        const Frag<VEC> x = load_frag<VEC>(grad_rows + (size_t)p * D, d0, D);
+    int64_t p = (j / PIECE + 1) * PIECE;
+    if (p >= B || ks[p] != row) return t;                // the common case: a single piece
+    for (;;) {
+        bool same[8];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) t.v[q] += x.v[q];
-        gb += grad_bias[p];
+        for (int q = 0; q < 8; ++q) {
+            const int64_t pp = p + (int64_t)q * PIECE;
+            same[q] = (pp < B) && (ks[pp] == row);
+        }
+        Frag<VEC> x[8];
+        float xb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t pp = (p + (int64_t)q * PIECE < B) ? p + (int64_t)q * PIECE : j;   // safe address
+            x[q] = load_frag<VEC>(grad_rows + (size_t)pp * D, d0, D);
+            xb[q] = grad_bias[pp];
+        }
+        bool go = true;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            go = go && same[q];                          // pieces are contiguous: stop at the first miss
+            if (go) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) t.v[e] += x[q].v[e];
+                gb += xb[q];
+            }
+        }
+        if (!go) break;
+        p += 8 * (int64_t)PIECE;
     }
     return t;
 }
