@@ -104,6 +104,12 @@ int tfr_forward(tfr_model* m, const int32_t* user, const int32_t* item, int64_t 
 int tfr_eval(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
              int64_t batch, double* sum_sq_err_out, int64_t* n_equal_out);
 
+/* the validation set kept in HBM (svd_train_val.py:33-38 feeds it whole, every epoch):
+ * upload once, evaluate with no host data in the loop.  n_out = number of ratings. */
+int tfr_upload_eval_triples(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
+                            int64_t n);
+int tfr_eval_resident(tfr_model* m, double* sum_sq_err_out, int64_t* n_equal_out, int64_t* n_out);
+
 /* ---- one minibatch: sess.run([train_op, logits, infer], feed_dict) - svd_train_val.py:66-72;
  *      ops.py:81-89 (regulariser), ops.py:118-153 (loss, minimize).
  *      logits_out = pre-update logits of this batch; loss_out = data term only

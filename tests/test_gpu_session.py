@@ -144,3 +144,33 @@ def test_device_initialisers_have_the_reference_distributions():
         assert abs(x.std() / sd - 0.8796) < 0.02            # std of a normal truncated at 2 sigma
     assert abs(float(t[L.MU])) <= np.sqrt(3) + 1e-6
     assert not np.array_equal(t[L.P][:100], t[L.Q][:100])
+
+
+def test_resident_driver_and_device_eval(tmp_path):
+    """SURVEY 8f #1: resident store + resident validation set; device-side RMSE == host RMSE."""
+    import json
+    import tfrecomm_amd as T
+    U, I = 300, 200
+    train, val = svd_train_val.synthetic_frames(U, I, 40000, seed=5)
+    np.random.seed(13575)
+    lines = []
+    rows = svd_train_val.svd_resident(train, val, user_num=U, item_num=I, dim=16, batch_size=1000, epoch_max=5,
+                                      learning_rate=5e-3, reg=0.02, json_log=str(tmp_path / "log.jsonl"), log=lines.append)
+    assert lines[0] == "epoch train_error val_error elapsed_time" and len(rows) == 5
+    assert rows[0][2] > 2.0 and rows[-1][2] < rows[1][2] < rows[0][2]
+    recs = [json.loads(x) for x in open(str(tmp_path / "log.jsonl"))]
+    assert [r["epoch"] for r in recs] == list(range(5)) and all(r["ratings_per_sec"] > 0 for r in recs)
+    # device-side metric against the host computation on the same model
+    rs = np.random.RandomState(0)
+    t = rand_tables(rs, U, I, 16)
+    with T.SvdModel(U, I, 16) as m:
+        m.set_tables(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        m.upload_eval_triples(val["user"], val["item"], val["outcome"])
+        sse, neq, n = m.eval_resident()
+        logits = m.forward(val["user"], val["item"]).astype(np.float64)
+    assert n == len(val["user"])
+    want = float(np.sum((logits - val["outcome"]) ** 2))
+    assert abs(sse - want) <= 1e-5 * want
+    with T.SvdModel(U, I, 16) as m:
+        with pytest.raises(T.TfrError):
+            m.eval_resident()

@@ -74,6 +74,10 @@ struct tfr_model {
     int64_t N = 0;
     int64_t* d_ids = nullptr;
     int64_t n_ids = 0;
+    // resident validation set (svd_train_val.py:33-38: the whole set is one batch)
+    int32_t *ev_u = nullptr, *ev_i = nullptr;
+    float* ev_r = nullptr;
+    int64_t ev_n = 0;
     // profiling
     bool prof = false;
     std::vector<ProfEvent> events;
@@ -269,7 +273,7 @@ int tfr_destroy(tfr_model* m) {
     for (int t = 0; t < 5; ++t) { dfree(m->w[t]); dfree(m->m[t]); dfree(m->v[t]); }
     dfree(m->map_u); dfree(m->map_i); dfree(m->dg_p); dfree(m->dg_q); dfree(m->dg_bu); dfree(m->dg_bi); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
     dfree(m->store);
-    dfree(m->d_ids);
+    dfree(m->d_ids); dfree(m->ev_u); dfree(m->ev_i); dfree(m->ev_r);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
     return TFR_OK;
@@ -803,6 +807,24 @@ int tfr_forward(tfr_model* m, const int32_t* u, const int32_t* i, int64_t B, flo
     return check_device_error(m);
 }
 
+static int eval_device(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
+                       double* sse_out, int64_t* neq_out) {
+    int nblk = 0, rc;
+    if ((rc = run_forward(m, MODE_EVAL, du, di, dr, B, nullptr, nullptr, &nblk))) return rc;
+    std::vector<float> part((size_t)nblk * 4);
+    HIPCHK(hipMemcpyAsync(part.data(), m->partials, part.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    if ((rc = check_device_error(m))) return rc;
+    double sse = 0.0;
+    int64_t neq = 0;
+    for (int b = 0; b < nblk; ++b) {
+        sse += (double)part[(size_t)b * 4 + 0];
+        neq += (int64_t)llround((double)part[(size_t)b * 4 + 1]);
+    }
+    if (sse_out) *sse_out = sse;
+    if (neq_out) *neq_out = neq;
+    return TFR_OK;
+}
+
 int tfr_eval(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t B,
              double* sse_out, int64_t* neq_out) {
     MODEL_ENTER(m);
@@ -816,20 +838,33 @@ int tfr_eval(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, i
     HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->d_r, r, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
-    int nblk = 0;
-    if ((rc = run_forward(m, MODE_EVAL, m->d_u, m->d_i, m->d_r, B, nullptr, nullptr, &nblk))) return rc;
-    std::vector<float> part((size_t)nblk * 4);
-    HIPCHK(hipMemcpyAsync(part.data(), m->partials, part.size() * 4, hipMemcpyDeviceToHost, m->stream));
-    if ((rc = check_device_error(m))) return rc;
-    double sse = 0.0;
-    int64_t neq = 0;
-    for (int b = 0; b < nblk; ++b) {
-        sse += (double)part[(size_t)b * 4 + 0];
-        neq += (int64_t)llround((double)part[(size_t)b * 4 + 1]);
-    }
-    if (sse_out) *sse_out = sse;
-    if (neq_out) *neq_out = neq;
+    return eval_device(m, m->d_u, m->d_i, m->d_r, B, sse_out, neq_out);
+}
+
+int tfr_upload_eval_triples(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t N) {
+    MODEL_ENTER(m);
+    if (N < 1 || !u || !i || !r) return fail(TFR_ERR_ARG, "upload_eval_triples: need n >= 1 and non-null columns");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    dfree(m->ev_u); dfree(m->ev_i); dfree(m->ev_r);
+    m->ev_u = m->ev_i = nullptr; m->ev_r = nullptr; m->ev_n = 0;
+    int rc;
+    if ((rc = dmalloc(&m->ev_u, (size_t)N))) return rc;
+    if ((rc = dmalloc(&m->ev_i, (size_t)N))) return rc;
+    if ((rc = dmalloc(&m->ev_r, (size_t)N))) return rc;
+    HIPCHK(hipMemcpyAsync(m->ev_u, u, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->ev_i, i, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->ev_r, r, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->ev_n = N;
+    if ((rc = ensure_capacity(m, 1))) return rc;
     return TFR_OK;
+}
+
+int tfr_eval_resident(tfr_model* m, double* sse_out, int64_t* neq_out, int64_t* n_out) {
+    MODEL_ENTER(m);
+    if (!m->ev_n) return fail(TFR_ERR_STATE, "no resident validation set: call tfr_upload_eval_triples first");
+    if (n_out) *n_out = m->ev_n;
+    return eval_device(m, m->ev_u, m->ev_i, m->ev_r, m->ev_n, sse_out, neq_out);
 }
 
 // ---- one minibatch ---------------------------------------------------------------------

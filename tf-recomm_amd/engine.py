@@ -123,6 +123,16 @@ class SvdModel:
                                    C.byref(sse), C.byref(neq)))
         return sse.value, neq.value
 
+    def upload_eval_triples(self, users, items, rates):
+        u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
+        L.check(self._lib.tfr_upload_eval_triples(self._h, L.ptr_i32(u), L.ptr_i32(i), L.ptr_f32(r), u.size))
+
+    def eval_resident(self):
+        """(sum of squared errors, number of infer == rate, n) over the resident validation set."""
+        sse, neq, n = C.c_double(), C.c_int64(), C.c_int64()
+        L.check(self._lib.tfr_eval_resident(self._h, C.byref(sse), C.byref(neq), C.byref(n)))
+        return sse.value, neq.value, n.value
+
     def train_step(self, users, items, rates, want_logits=True):
         u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
         if not (u.shape == i.shape == r.shape) or u.ndim != 1:

@@ -90,6 +90,52 @@ def svd(train, test, *, user_num=None, item_num=None, dim=None, batch_size=None,
     return rows
 
 
+def svd_resident(train, test, *, user_num=None, item_num=None, dim=None, batch_size=None, epoch_max=None,
+                 learning_rate=None, reg=None, device=None, adam_mode="tf1", json_log=None, log=print):
+    """The same run with every input resident in HBM: the rating store and the
+    validation set are uploaded once, the host only draws the reference's ``randint`` id stream,
+    one epoch of minibatches is one C-ABI call, and the validation error is reduced on the device.
+    Prints the README rows and (optionally) writes one JSON line per epoch with ratings/sec."""
+    import json
+    from .engine import SvdModel
+    user_num, item_num = user_num or C.USER_NUM, item_num or C.ITEM_NUM
+    dim, batch_size = dim or C.DIM, batch_size or C.BATCH_SIZE
+    epoch_max = C.EPOCH_MAX if epoch_max is None else epoch_max
+    learning_rate = C.LEARNING_RATE if learning_rate is None else learning_rate
+    reg = C.LAMBDA_REG if reg is None else reg
+    device = C.DEVICE if device is None else device
+    n_train = len(train["user"])
+    nb_batches = n_train // batch_size                                   # svd_train_val.py:24
+    rows, fh = [], open(json_log, "w") if json_log else None
+    with SvdModel(user_num, item_num, dim, optimizer="adam", adam_mode=adam_mode, lr=learning_rate, reg=reg,
+                  device=device) as m:
+        m.init_tables(seed=C.SEED)
+        m.upload_triples(train["user"], train["item"], train["outcome"])
+        m.upload_eval_triples(test["user"], test["item"], test["outcome"])
+        log("{} {} {} {}".format("epoch", "train_error", "val_error", "elapsed_time"))
+        start = time.time()
+        for epoch in range(epoch_max):
+            # epoch 0 of the reference is evaluated after ONE step (svd_train_val.py:106); later rows
+            # after nb_batches more
+            steps = 1 if epoch == 0 else nb_batches
+            ids = np.random.randint(0, n_train, (steps, batch_size))      # dataio.py:115, one draw per step
+            loss = m.train_steps_resident(ids, batch_size)                # data term 0.5*sum(err^2) per step
+            train_err = float(np.sqrt(2.0 * loss.astype(np.float64).sum() / (steps * batch_size)))
+            sse, _, n = m.eval_resident()
+            end = time.time()
+            row = (epoch, train_err, float(np.sqrt(sse / n)), end - start)
+            rows.append(row)
+            log("{:3d} {:f} {:f} {:f}(s)".format(*row))
+            if fh:
+                fh.write(json.dumps(dict(epoch=epoch, train_error=row[1], val_error=row[2], elapsed_time=row[3],
+                                         ratings_per_sec=steps * batch_size / max(row[3], 1e-9))) + "\n")
+                fh.flush()
+            start = end
+    if fh:
+        fh.close()
+    return rows
+
+
 def synthetic_frames(user_num, item_num, n, seed=C.SEED):
     """ML-1M-shaped ratings from a low-rank ground truth (no dataset ships; no network)."""
     rs = np.random.RandomState(seed)
