@@ -95,6 +95,24 @@ def algo_bytes(kernel, B, D, U, I, adam_mode):
     return 0
 
 
+def profiled_traffic(kernel_substr):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC summary (profiles/r01_pmc_summary.csv):
+    TCC_EA0_RDREQ x 128 B (= FETCH_SIZE x 2, the gfx950 correction for 16-byte-per-lane reads) +
+    WRITE_SIZE.  bench.py cannot collect counters itself; None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    rd = wr = None
+    for line in open(path):
+        f = line.strip().split(",")
+        if len(f) >= 4 and kernel_substr in line:
+            if f[-5] == "TCC_EA0_RDREQ_sum":
+                rd = float(f[-3]) * 128.0
+            if f[-5] == "WRITE_SIZE":
+                wr = float(f[-3]) * 1024.0
+    return None if rd is None else rd + (wr or 0.0)
+
+
 def time_cpu_baseline(wl, train, ids, budget_s=12.0):
     """oracle/svd_oracle.c on the same batches: scalar port, 1 thread."""
     from oracle.c_oracle import COracle
@@ -163,7 +181,9 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
     copy_gbs = 2 * x.numel() * 4 / (min(ev[i].elapsed_time(ev[i + 1]) for i in range(10)) * 1e-3) / 1e9
     del x, y
     return dict(checksum=chk, kernel="k_forward<32,4,infer>", workload="10M users x 1M items, dim=128, batch=262144, uniform ids",
-                bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None,
+                bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                traffic=profiled_traffic("k_forward<32, 4, 0") if (U, I, D, B) == (10_000_000, 1_000_000, 128, 262144) else None,
+                traffic_source="profiles/r01_pmc_summary.csv (rocprofv3 --pmc, separate passes)",
                 algorithmic_bytes_per_launch=per_launch, avg_launch_us=ms / n * 1e3,
                 ratings_per_s=B * n / (ms * 1e-3), wall_ratings_per_s=B * steps / wall,
                 device_copy_GBps=copy_gbs, frac_of_device_copy=gbs / copy_gbs)
@@ -185,7 +205,7 @@ def fm_forward_bench(device, steps=50, warmup=5, F=1_000_000, D=64, n=1 << 20, n
     indptr = (torch.arange(n + 1, device=dev, dtype=torch.int64) * nnz).contiguous()
     out = torch.empty(n, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    m = T.FmModel(F, D, device=device)
+    m = T.FmModel(F, D, device=device, loss="nll", optimizer="sgd", lr=1e-3, reg=1e-4)
     m.init(seed=3, stddev=0.1)
     ms = []
     for s in range(warmup + steps):
@@ -193,6 +213,15 @@ def fm_forward_bench(device, steps=50, warmup=5, F=1_000_000, D=64, n=1 << 20, n
         t = m.sync()
         if s >= warmup:
             ms.append(t)
+    # training step on the same rows (SGD): forward+coefficients, radix sort of the non-zeros, segmented reduce
+    yt = (torch.rand(n, device=dev, generator=g) < 0.5).float()
+    tms = []
+    for s in range(3 + min(steps, 20)):
+        m.train_step_dev(indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), yt.data_ptr(), n, n * nnz)
+        t = m.sync()
+        if s >= 3:
+            tms.append(t)
+    train_ms = sum(tms) / len(tms)
     m.close()
     avg = sum(ms) / len(ms)
     per_launch = n * (nnz * (4 * D + 12) + 4)
@@ -202,7 +231,9 @@ def fm_forward_bench(device, steps=50, warmup=5, F=1_000_000, D=64, n=1 << 20, n
                 dtype="f32", data="synthetic", config=dict(workload="c5: FM forward F=1M D=64 rows=2^20 nnz=8"),
                 roofline=dict(kernel="k_fm_forward<16,4>", bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                               frac=gbs / HBM_PEAK_GBS, traffic=None, algorithmic_bytes_per_launch=per_launch,
-                              avg_launch_us=avg * 1e3), cpu_baseline=None, checksum=float(out.double().sum().item()))
+                              avg_launch_us=avg * 1e3), cpu_baseline=None, checksum=float(out.double().sum().item()),
+                train=dict(note="one SGD minibatch on the same 2^20 rows (8.4M non-zeros), whole step incl. sort",
+                           ms_per_step=train_ms, rows_per_s=n / (train_ms * 1e-3)))
 
 
 def main():

@@ -198,14 +198,29 @@ int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t ba
  *      (fm.py:154-155, fm_mangaki.py:39-45); here it is uploaded or initialised on the device.
  *      CSR uses scipy.sparse's layout: indptr int64 [n_rows+1], indices int32, data f32. */
 typedef struct tfr_fm tfr_fm;
-int tfr_fm_create(tfr_fm** out, int64_t n_features, int32_t dim, int32_t device);
+/* opts (NULL = classification / SGD defaults): loss, optimizer (SGD or Adam - always the lazy,
+ * touched-rows form), lr, reg, device.  The model is a regular model underneath: V = feature rows,
+ * W = their bias column, mu = bias_global. */
+int tfr_fm_create(tfr_fm** out, int64_t n_features, int32_t dim, const tfr_opts* opts);
 int tfr_fm_destroy(tfr_fm* m);
 int tfr_fm_set(tfr_fm* m, float mu, const float* W, const float* V);          /* host pointers */
+int tfr_fm_get(tfr_fm* m, float* mu, float* W, float* V);                      /* any may be NULL */
 int tfr_fm_init(tfr_fm* m, uint64_t seed, float stddev);                       /* random W, V on device */
 int tfr_fm_forward(tfr_fm* m, const int64_t* indptr, const int32_t* indices, const float* data,
                    int64_t n_rows, float* out);                                /* host CSR, synchronous */
 int tfr_fm_forward_dev(tfr_fm* m, const int64_t* d_indptr, const int32_t* d_indices,
                        const float* d_data, int64_t n_rows, float* d_out);     /* device CSR, async */
+/* One minibatch of FM training.  NOT a restatement of reference code: the
+ * reference trains this model in the external libFM binary by MCMC (fm.py:104-110,154-155).
+ * Per non-zero (row r, feature j, x), s_r = x V, g_r = d loss / d y_r:
+ *   dV_j += g_r x (s_r - x V_j) + reg V_j;  dW_j += g_r x + reg W_j;  dmu += g_r
+ * applied with SGD or lazy Adam; deterministic (sorted segmented reduce, no atomics).
+ * pred_out = predictions before the update, loss_out = data loss; either may be NULL. */
+int tfr_fm_train_step(tfr_fm* m, const int64_t* indptr, const int32_t* indices, const float* data,
+                      const float* y, int64_t n_rows, float* pred_out, float* loss_out);
+int tfr_fm_train_step_dev(tfr_fm* m, const int64_t* d_indptr, const int32_t* d_indices,
+                          const float* d_data, const float* d_y, int64_t n_rows, int64_t nnz,
+                          float* d_pred /* may be NULL */);
 int tfr_fm_sync(tfr_fm* m, float* last_kernel_ms);
 const char* tfr_fm_last_error(void);
 

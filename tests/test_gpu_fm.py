@@ -64,3 +64,65 @@ def test_fm_errors():
             m.fma(sp.identity(7, format="csr"))
     with pytest.raises(T.TfrError):
         T.FmModel(10, 300)
+
+
+# ------------------------------------------------------------------ FM training
+def _random_design(rs, n, F, nnz, hot=20):
+    """CSR rows with a few very hot features (long runs in the backward) and an empty row."""
+    rows, cols, vals = [], [], []
+    for r in range(n):
+        k = 0 if r == 3 else rs.randint(1, nnz + 1)
+        picks = set(rs.randint(0, hot, k // 2 + 1).tolist()[:k]) | set(rs.randint(0, F, k).tolist())
+        picks = sorted(picks)[:k]
+        rows += [r] * len(picks)
+        cols += picks
+        vals += rs.randint(1, 4, len(picks)).tolist()
+    return sp.csr_matrix((np.array(vals, np.float32), (rows, cols)), shape=(n, F))
+
+
+@pytest.mark.parametrize("loss", ["mse", "nll"])
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+@pytest.mark.parametrize("F,D,n,nnz", [(400, 16, 700, 6), (5000, 64, 3000, 8), (90, 5, 257, 4)])
+def test_fm_training_matches_oracle(loss, optimizer, F, D, n, nnz):
+    rs = np.random.RandomState(F + n)
+    V0 = rs.normal(0, 0.1, (F, D)).astype(np.float32)
+    W0 = rs.normal(0, 0.1, F).astype(np.float32)
+    mu0 = np.float32(0.1)
+    lr, lam = (0.02, 0.01) if optimizer == "sgd" else (0.002, 0.01)   # Adam error scales with lr (sign-like first steps)
+    V, W, mu = V0.astype(np.float64), W0.astype(np.float64), np.float64(mu0)
+    state = so.fm_adam_state(F, D) if optimizer == "adam" else None
+    with T.FmModel(F, D, loss=loss, optimizer=optimizer, lr=lr, reg=lam) as m:
+        m.set(mu0, W0, V0)
+        for s in range(3):
+            X = _random_design(rs, n, F, nnz)
+            y = (rs.rand(n) < 0.5).astype(np.float32) if loss == "nll" else rs.normal(0, 1, n).astype(np.float32)
+            pred, lossv = m.train_step(X, y)
+            want_pred, want_loss, mu = so.fm_train_step(mu, W, V, X.indptr, X.indices, X.data.astype(np.float64),
+                                                        y.astype(np.float64), lr, lam, loss, optimizer, state)
+            # hot features sum ~400 fp32 terms per step; Adam's normalisation amplifies their rounding
+            tol = (1e-4 if optimizer == "adam" else 3e-5) * (s + 1)
+            assert_close(pred, want_pred, rtol=tol, what="pred step %d" % s)
+            assert_close(lossv, want_loss, rtol=tol, what="loss step %d" % s)
+        gmu, gW, gV = m.get()
+    assert_close(gV, V, rtol=4e-4, what="V")
+    assert_close(gW, W, rtol=4e-4, what="W")
+    assert abs(gmu - mu) <= 2e-4 * max(1.0, abs(mu))
+    assert not np.array_equal(gV, V0)
+
+
+def test_fm_training_is_deterministic_and_learns():
+    rs = np.random.RandomState(1)
+    F, D, n = 2000, 16, 4000
+    Vt = rs.normal(0, 0.3, (F, 4))
+    X = _random_design(rs, n, F, 6)
+    logit = np.array([0.5 * ((X[r].toarray() @ Vt) ** 2).sum() - 1.0 for r in range(n)])
+    y = (rs.rand(n) < 1 / (1 + np.exp(-logit))).astype(np.float32)
+    outs = []
+    for rep in range(2):
+        with T.FmModel(F, D, loss="nll", optimizer="adam", lr=0.05, reg=0.001) as m:
+            m.init(seed=4, stddev=0.05)
+            losses = [m.train_step(X, y)[1] for _ in range(30)]
+            outs.append((losses, m.get()))
+    assert outs[0][0] == outs[1][0]                                  # bit-identical run to run
+    assert np.array_equal(outs[0][1][2], outs[1][1][2])
+    assert outs[0][0][-1] < 0.8 * outs[0][0][0]                      # the data loss falls

@@ -84,9 +84,12 @@ SIGNATURES = {
     "tfr_dp_local_grads": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _p]),
     "tfr_dp_apply": (C.c_int, [_p, _p]),
     "tfr_staged_ids_devptr": (C.c_int, [_p, C.POINTER(_p), _i64p]),
-    "tfr_fm_create": (C.c_int, [C.POINTER(_p), C.c_int64, C.c_int32, C.c_int32]),
+    "tfr_fm_create": (C.c_int, [C.POINTER(_p), C.c_int64, C.c_int32, C.POINTER(TfrOpts)]),
     "tfr_fm_destroy": (C.c_int, [_p]),
     "tfr_fm_set": (C.c_int, [_p, C.c_float, _f32p, _f32p]),
+    "tfr_fm_get": (C.c_int, [_p, _f32p, _f32p, _f32p]),
+    "tfr_fm_train_step": (C.c_int, [_p, _i64p, _i32p, _f32p, _f32p, C.c_int64, _f32p, _f32p]),
+    "tfr_fm_train_step_dev": (C.c_int, [_p, _p, _p, _p, _p, C.c_int64, C.c_int64, _p]),
     "tfr_fm_init": (C.c_int, [_p, C.c_uint64, C.c_float]),
     "tfr_fm_forward": (C.c_int, [_p, _i64p, _i32p, _f32p, C.c_int64, _f32p]),
     "tfr_fm_forward_dev": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p]),

@@ -83,6 +83,7 @@ struct tfr_model {
     std::vector<ProfEvent> events;
     double prof_ms[TFR_K_COUNT];
     int64_t prof_n[TFR_K_COUNT];
+    float prof_overhead_ms = 0.f;     // elapsed time of an empty event pair on this stream
 };
 
 // ---------------------------------------------------------------------------------------
@@ -128,6 +129,8 @@ static int drain_profile(tfr_model* m) {
     for (auto& e : m->events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            ms -= m->prof_overhead_ms;                   // what an empty start/stop pair measures
+            if (ms < 0.f) ms = 0.f;
             m->prof_ms[e.kid] += ms;
             m->prof_n[e.kid] += 1;
         }
@@ -480,6 +483,22 @@ int tfr_profile(tfr_model* m, int32_t enable) {
     if (enable) {
         memset(m->prof_ms, 0, sizeof(m->prof_ms));
         memset(m->prof_n, 0, sizeof(m->prof_n));
+        // calibrate: median-of-9 elapsed time of back-to-back event pairs with nothing in between
+        float v[9];
+        int n = 0;
+        for (int k = 0; k < 9; ++k) {
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) != hipSuccess) break;
+            if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); break; }
+            (void)hipEventRecord(e0, m->stream);
+            (void)hipEventRecord(e1, m->stream);
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) v[n++] = ms;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        for (int x = 1; x < n; ++x) for (int y = x; y > 0 && v[y] < v[y - 1]; --y) { float t = v[y]; v[y] = v[y - 1]; v[y - 1] = t; }
+        m->prof_overhead_ms = n ? v[n / 2] : 0.f;
     }
     m->prof = enable != 0;
     return TFR_OK;
@@ -1452,6 +1471,304 @@ int tfr_staged_ids_devptr(tfr_model* m, void** ptr, int64_t* n) {
     MODEL_ENTER(m);
     if (ptr) *ptr = m->d_ids;
     if (n) *n = m->n_ids;
+    return TFR_OK;
+}
+
+}  // extern "C"
+
+// ---- second-order FM (BASELINE config 5) -------------------------------------
+// The handle wraps a regular model: V = its user_features [F,D], W = its user_bias [F],
+// mu = its bias_global; so the FM backward reuses the radix sort, the segmented reduce (K3) and
+// the fused SGD / lazy-Adam apply unchanged.
+struct tfr_fm {
+    tfr_model* m = nullptr;
+    int64_t cap_rows = 0, cap_nnz = 0, s_cap = 0;
+    int64_t* d_indptr = nullptr;
+    int32_t* d_indices = nullptr;
+    float *d_data = nullptr, *d_y = nullptr, *d_out = nullptr, *s_rows = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int fm_stage_csr(tfr_fm* f, const int64_t* indptr, const int32_t* indices, const float* data,
+                        const float* y, int64_t n_rows, int64_t* nnz_out) {
+    tfr_model* m = f->m;
+    const int64_t nnz = indptr[n_rows];
+    if (nnz < 0 || indptr[0] != 0) return fail(TFR_ERR_ARG, "indptr must start at 0 and be non-decreasing");
+    for (int64_t r = 0; r < n_rows; ++r)
+        if (indptr[r + 1] < indptr[r]) return fail(TFR_ERR_ARG, "indptr must be non-decreasing");
+    if (nnz > 0 && (!indices || !data)) return fail(TFR_ERR_ARG, "null indices/data");
+    if (n_rows > f->cap_rows) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(f->d_indptr); dfree(f->d_out); dfree(f->d_y);
+        f->d_indptr = nullptr; f->d_out = nullptr; f->d_y = nullptr; f->cap_rows = 0;
+        int rc;
+        if ((rc = dmalloc(&f->d_indptr, (size_t)n_rows + 1))) return rc;
+        if ((rc = dmalloc(&f->d_out, (size_t)n_rows))) return rc;
+        if ((rc = dmalloc(&f->d_y, (size_t)n_rows))) return rc;
+        f->cap_rows = n_rows;
+    }
+    if (nnz > f->cap_nnz) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(f->d_indices); dfree(f->d_data);
+        f->d_indices = nullptr; f->d_data = nullptr; f->cap_nnz = 0;
+        int rc;
+        if ((rc = dmalloc(&f->d_indices, (size_t)nnz))) return rc;
+        if ((rc = dmalloc(&f->d_data, (size_t)nnz))) return rc;
+        f->cap_nnz = nnz;
+    }
+    HIPCHK(hipMemcpyAsync(f->d_indptr, indptr, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, m->stream));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpyAsync(f->d_indices, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(f->d_data, data, (size_t)nnz * 4, hipMemcpyHostToDevice, m->stream));
+    }
+    if (y) HIPCHK(hipMemcpyAsync(f->d_y, y, (size_t)n_rows * 4, hipMemcpyHostToDevice, m->stream));
+    *nnz_out = nnz;
+    return TFR_OK;
+}
+
+static int fm_forward_core(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_indices, const float* d_data,
+                           int64_t n_rows, float* d_out) {
+    tfr_model* m = f->m;
+    FmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.V = m->w[TFR_P]; a.W = m->w[TFR_BU]; a.mu = m->w[TFR_MU];
+    a.indptr = d_indptr; a.indices = d_indices; a.data = d_data; a.out = d_out; a.err = m->d_err;
+    a.n_rows = n_rows; a.F = m->U; a.D = m->D;
+    (void)hipEventRecord(f->ev0, m->stream);
+    launch_fm(a, false, m->G, m->VEC, fm_grid(n_rows, m->G, false), m->stream);
+    (void)hipEventRecord(f->ev1, m->stream);
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
+// one minibatch: forward (+ s, g, per-entry coefficients) -> radix sort of the non-zeros by
+// feature id -> segmented reduce with fused SGD / lazy Adam on V and W -> mu
+static int fm_train_core(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_indices, const float* d_data,
+                         const float* d_y, int64_t n_rows, int64_t nnz, float* d_pred, float* out3) {
+    tfr_model* m = f->m;
+    const tfr_opts& o = m->o;
+    const bool adam = o.optimizer == TFR_OPT_ADAM;
+    if (adam && o.adam_mode != TFR_ADAM_LAZY) return fail(TFR_ERR_STATE, "FM training supports SGD and lazy Adam");
+    int rc;
+    if ((rc = ensure_capacity(m, nnz > 0 ? nnz : 1))) return rc;
+    if (n_rows * m->D > f->s_cap) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(f->s_rows);
+        f->s_rows = nullptr; f->s_cap = 0;
+        if ((rc = dmalloc(&f->s_rows, (size_t)n_rows * m->D))) return rc;
+        f->s_cap = n_rows * m->D;
+    }
+    const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
+    hipStream_t s = m->stream;
+    FmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.V = m->w[TFR_P]; a.W = m->w[TFR_BU]; a.mu = m->w[TFR_MU];
+    a.indptr = d_indptr; a.indices = d_indices; a.data = d_data; a.out = d_pred; a.err = m->d_err;
+    a.y = d_y; a.s_rows = f->s_rows; a.ent_row = m->d_i; a.ent_a = m->d_g; a.ent_b = m->d_r; a.partials = m->partials;
+    a.n_rows = n_rows; a.F = m->U; a.D = m->D; a.loss = o.loss; a.lam = o.reg;
+    const int grid = fm_grid(n_rows, m->G, true);
+    (void)hipEventRecord(f->ev0, s);
+    {
+        Prof p(m, TFR_K_FORWARD);
+        launch_fm(a, true, m->G, m->VEC, grid, s);
+    }
+    HIPCHK(hipGetLastError());
+    if (nnz > 0) {
+        const int32_t* keys[2] = {d_indices, nullptr};
+        const int bits[2] = {m->bits_u, 0};
+        int32_t* ks[2] = {m->ks_u, nullptr};
+        int32_t* ps[2] = {m->ps_u, nullptr};
+        {
+            Prof p(m, TFR_K_SORT);
+            if ((rc = radix_sort_columns(m, 1, keys, bits, ks, ps, nnz))) return rc;
+        }
+        RedPair pr;
+        RedArgs& r = pr.a[0];
+        memset(&r, 0, sizeof(r));
+        r.err = m->d_err; r.B = nnz; r.D = m->D; r.side = 0; r.reg_bias = 1;
+        r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
+        r.ks = m->ks_u; r.ps = m->ps_u; r.other = m->d_i; r.g = m->d_g; r.lam_arr = m->d_r;
+        r.own = m->w[TFR_P]; r.partner = f->s_rows; r.own_bias = m->w[TFR_BU];
+        r.own_w = m->w[TFR_P]; r.m = m->m[TFR_P]; r.v = m->v[TFR_P];
+        r.bias_w = m->w[TFR_BU]; r.bias_m = m->m[TFR_BU]; r.bias_v = m->v[TFR_BU];
+        r.grad_rows = m->gq + (size_t)m->cap * m->D; r.grad_bias = m->gbp;
+        {
+            Prof p(m, TFR_K_REDUCE_USER);
+            launch_seg_reduce(pr, 1, adam ? RMODE_ADAM : RMODE_SGD, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        ApplyPair app;
+        ApplyArgs& ap = app.a[0];
+        memset(&ap, 0, sizeof(ap));
+        ap.err = m->d_err; ap.B = nnz; ap.D = m->D; ap.only_split = 1;
+        ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
+        ap.ks = m->ks_u; ap.grad_rows = r.grad_rows; ap.grad_bias = m->gbp;
+        ap.w = m->w[TFR_P]; ap.m = m->m[TFR_P]; ap.v = m->v[TFR_P];
+        ap.bias_w = m->w[TFR_BU]; ap.bias_m = m->m[TFR_BU]; ap.bias_v = m->v[TFR_BU];
+        {
+            Prof p(m, TFR_K_APPLY);
+            launch_apply_rows(app, 1, adam ? 0 : 1, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    FinArgs fin;
+    memset(&fin, 0, sizeof(fin));
+    fin.partials = m->partials; fin.nblk = grid; fin.scalars = m->scalars; fin.out = out3;
+    fin.mu = m->w[TFR_MU]; fin.mu_m = m->m[TFR_MU]; fin.mu_v = m->v[TFR_MU]; fin.err = m->d_err;
+    fin.update_mu = 1; fin.opt = adam ? 0 : 1;
+    fin.alpha = alpha; fin.b1 = o.beta1; fin.b2 = o.beta2; fin.eps = o.eps; fin.lr = o.lr;
+    {
+        Prof p(m, TFR_K_FINALIZE);
+        launch_finalize(fin, s);
+    }
+    (void)hipEventRecord(f->ev1, s);
+    HIPCHK(hipGetLastError());
+    if (adam) {
+        m->b1p *= o.beta1;
+        m->b2p *= o.beta2;
+    }
+    m->step += 1;
+    return TFR_OK;
+}
+
+extern "C" {
+
+const char* tfr_fm_last_error(void) { return g_err; }
+
+int tfr_fm_destroy(tfr_fm* f) {
+    if (!f) return TFR_OK;
+    if (f->m) {
+        (void)hipSetDevice(f->m->device);
+        (void)hipStreamSynchronize(f->m->stream);
+    }
+    dfree(f->d_indptr); dfree(f->d_indices); dfree(f->d_data); dfree(f->d_y); dfree(f->d_out); dfree(f->s_rows);
+    if (f->ev0) (void)hipEventDestroy(f->ev0);
+    if (f->ev1) (void)hipEventDestroy(f->ev1);
+    tfr_destroy(f->m);
+    delete f;
+    return TFR_OK;
+}
+
+int tfr_fm_create(tfr_fm** out, int64_t n_features, int32_t dim, const tfr_opts* opts) {
+    if (!out) return fail(TFR_ERR_ARG, "out is null");
+    *out = nullptr;
+    tfr_opts o;
+    if (opts) o = *opts;
+    else {
+        tfr_default_opts(&o);
+        o.loss = TFR_LOSS_NLL;          // fm.py:104 task = 'classification'
+        o.optimizer = TFR_OPT_SGD;
+        o.lr = 0.01f; o.reg = 0.0f;
+    }
+    if (o.optimizer == TFR_OPT_ADAM) o.adam_mode = TFR_ADAM_LAZY;
+    tfr_fm* f = new (std::nothrow) tfr_fm();
+    if (!f) return fail(TFR_ERR_NOMEM, "host allocation failed");
+    int rc = tfr_create(&f->m, n_features, 1, dim, &o);
+    if (rc == TFR_OK && (hipEventCreate(&f->ev0) != hipSuccess || hipEventCreate(&f->ev1) != hipSuccess))
+        rc = fail(TFR_ERR_HIP, "event creation failed");
+    if (rc) {
+        char keep[512];
+        strncpy(keep, g_err, sizeof(keep));
+        tfr_fm_destroy(f);
+        strncpy(g_err, keep, sizeof(g_err));
+        return rc;
+    }
+    *out = f;
+    return TFR_OK;
+}
+
+int tfr_fm_set(tfr_fm* f, float mu, const float* W, const float* V) {
+    if (!f || !W || !V) return fail(TFR_ERR_ARG, "null argument");
+    int rc = tfr_set_table(f->m, TFR_MU, &mu, 1);
+    if (!rc) rc = tfr_set_table(f->m, TFR_BU, W, f->m->U);
+    if (!rc) rc = tfr_set_table(f->m, TFR_P, V, f->m->U * f->m->D);
+    return rc;
+}
+
+int tfr_fm_get(tfr_fm* f, float* mu, float* W, float* V) {
+    if (!f) return fail(TFR_ERR_ARG, "null model");
+    int rc = TFR_OK;
+    if (mu) rc = tfr_get_table(f->m, TFR_MU, mu, 1);
+    if (!rc && W) rc = tfr_get_table(f->m, TFR_BU, W, f->m->U);
+    if (!rc && V) rc = tfr_get_table(f->m, TFR_P, V, f->m->U * f->m->D);
+    return rc;
+}
+
+int tfr_fm_init(tfr_fm* f, uint64_t seed, float stddev) {
+    if (!f) return fail(TFR_ERR_ARG, "null model");
+    tfr_model* m = f->m;
+    HIPCHK(hipSetDevice(m->device));
+    launch_init_trunc_normal(m->w[TFR_P], m->n[TFR_P], stddev, seed * 2 + 0, m->stream);
+    launch_init_trunc_normal(m->w[TFR_BU], m->n[TFR_BU], stddev, seed * 2 + 1, m->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(m->w[TFR_MU], 0, 4, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return TFR_OK;
+}
+
+int tfr_fm_forward_dev(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_indices, const float* d_data,
+                       int64_t n_rows, float* d_out) {
+    if (!f || n_rows < 0 || (n_rows > 0 && (!d_indptr || !d_out))) return fail(TFR_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(f->m->device));
+    if (n_rows == 0) return TFR_OK;
+    int rc = ensure_capacity(f->m, 1);
+    if (rc) return rc;
+    return fm_forward_core(f, d_indptr, d_indices, d_data, n_rows, d_out);
+}
+
+int tfr_fm_forward(tfr_fm* f, const int64_t* indptr, const int32_t* indices, const float* data,
+                   int64_t n_rows, float* out) {
+    if (!f || n_rows < 0 || (n_rows > 0 && (!indptr || !out))) return fail(TFR_ERR_ARG, "bad arguments");
+    tfr_model* m = f->m;
+    HIPCHK(hipSetDevice(m->device));
+    if (n_rows == 0) return TFR_OK;
+    int64_t nnz = 0;
+    int rc = fm_stage_csr(f, indptr, indices, data, nullptr, n_rows, &nnz);
+    if (rc) return rc;
+    if ((rc = fm_forward_core(f, f->d_indptr, f->d_indices, f->d_data, n_rows, f->d_out))) return rc;
+    HIPCHK(hipMemcpyAsync(out, f->d_out, (size_t)n_rows * 4, hipMemcpyDeviceToHost, m->stream));
+    return check_device_error(m);
+}
+
+int tfr_fm_train_step_dev(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_indices, const float* d_data,
+                          const float* d_y, int64_t n_rows, int64_t nnz, float* d_pred) {
+    if (!f || n_rows < 1 || nnz < 0 || !d_indptr || !d_y) return fail(TFR_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(f->m->device));
+    return fm_train_core(f, d_indptr, d_indices, d_data, d_y, n_rows, nnz, d_pred, nullptr);
+}
+
+int tfr_fm_train_step(tfr_fm* f, const int64_t* indptr, const int32_t* indices, const float* data, const float* y,
+                      int64_t n_rows, float* pred_out, float* loss_out) {
+    if (!f || n_rows < 1 || !indptr || !y) return fail(TFR_ERR_ARG, "bad arguments");
+    tfr_model* m = f->m;
+    HIPCHK(hipSetDevice(m->device));
+    int64_t nnz = 0;
+    int rc = fm_stage_csr(f, indptr, indices, data, y, n_rows, &nnz);
+    if (rc) return rc;
+    const int64_t step0 = m->step;
+    const float b1p0 = m->b1p, b2p0 = m->b2p;
+    if ((rc = fm_train_core(f, f->d_indptr, f->d_indices, f->d_data, f->d_y, n_rows, nnz, f->d_out, nullptr))) return rc;
+    float sc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pred_out) HIPCHK(hipMemcpyAsync(pred_out, f->d_out, (size_t)n_rows * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(sc, m->scalars, 16, hipMemcpyDeviceToHost, m->stream));
+    if ((rc = check_device_error(m))) {
+        rollback_step(m, step0, b1p0, b2p0);
+        return rc;
+    }
+    if (loss_out) *loss_out = sc[0];
+    return TFR_OK;
+}
+
+int tfr_fm_sync(tfr_fm* f, float* last_kernel_ms) {
+    if (!f) return fail(TFR_ERR_ARG, "null model");
+    HIPCHK(hipSetDevice(f->m->device));
+    int rc = check_device_error(f->m);
+    if (rc) return rc;
+    if (last_kernel_ms) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, f->ev0, f->ev1) != hipSuccess) ms = 0.f;
+        *last_kernel_ms = ms;
+    }
     return TFR_OK;
 }
 

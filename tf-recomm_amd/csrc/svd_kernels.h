@@ -38,6 +38,7 @@ struct RedArgs {
     float* grad_rows; float* grad_bias; int32_t* map;
     float* dense_rows; float* dense_bias;          // optional dense [rows,D] / [rows] gradient buffers
     const float* rows_in; const float* bias_in;    // sharded owner side: pre-reduced gradient rows
+    const float* lam_arr;                          // optional per-entry coefficient of the own row (FM)
     const int32_t* err;
     int64_t B;
     int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;
@@ -94,6 +95,19 @@ struct CSortArgs {
     int32_t ntiles;
     int64_t B;
 };
+
+// second-order FM forward on CSR rows (fm_kernels.hip); training extras are NULL for inference
+struct FmArgs {
+    const float* V; const float* W; const float* mu;
+    const int64_t* indptr; const int32_t* indices; const float* data;
+    float* out; int32_t* err;
+    const float* y; float* s_rows; int32_t* ent_row; float* ent_a; float* ent_b; float* partials;
+    int64_t n_rows, F;
+    int32_t D, loss;
+    float lam;
+};
+int fm_grid(int64_t n_rows, int G, bool train);
+void launch_fm(const FmArgs& a, bool train, int G, int VEC, int grid, hipStream_t s);
 
 // forward + csort rank pass in one launch (small tables)
 struct FrontArgs {

@@ -410,6 +410,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     } else if (valid) {
         const float gk = a.g[pos];
         const int32_t pid = a.other[pos];
+        const float lam_e = a.lam_arr ? a.lam_arr[pos] : a.lam;      // FM: lam - g x^2 per non-zero
         const Frag<VEC> x = load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
         o = load_frag<VEC>(a.own + roff, d0, D);
         ob = a.own_bias[row];
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             float xv = x.v[q];
             if (a.side == 0) { if (a.item_abs) xv = fabsf(xv); }
             else if (a.item_abs) xv = xv * ((o.v[q] > 0.f) ? 1.f : ((o.v[q] < 0.f) ? -1.f : 0.f));
-            t.v[q] = gk * xv + a.lam * o.v[q];
+            t.v[q] = gk * xv + lam_e * o.v[q];
         }
         tb = a.reg_bias ? (gk + a.lam * ob) : gk;
     }
