@@ -348,7 +348,10 @@ def main():
     launches_per_step = kern[dom]["launches"] / kp
     avg_s = kern[dom]["total_ms"] / kern[dom]["launches"] * 1e-3
     gbs = per_launch / launches_per_step / avg_s / 1e9 if avg_s > 0 else 0.0
-    roofline = dict(kernel=dom, bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+    symbols = {"forward": "k_front (forward + fused gather + csort rank) / k_forward", "sort": "k_csort_scan(+finalize) + k_csort_scatter / k_rsort_*",
+               "reduce_item": "k_seg_reduce<scratch> (tf1: item+user sides in one launch)", "reduce_user": "k_seg_reduce<adam|sgd> (fused apply)",
+               "apply": "k_adam_dense (tf1 sweep, both tables) / k_apply_rows", "finalize": "k_finalize", "gather": "k_gather_triples"}
+    roofline = dict(kernel=dom, kernel_symbol=symbols.get(dom, dom), bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
                     traffic=None, algorithmic_bytes_per_step=per_launch, avg_launch_us=avg_s * 1e6,
                     note="tables (2.6 MB + Adam state) are L2/Infinity-Cache resident at this size; "
                          "the HBM-bound measurement is north_star_forward",
