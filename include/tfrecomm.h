@@ -224,6 +224,24 @@ int tfr_fm_train_step_dev(tfr_fm* m, const int64_t* d_indptr, const int32_t* d_i
 int tfr_fm_sync(tfr_fm* m, float* last_kernel_ms);
 const char* tfr_fm_last_error(void);
 
+/* ---- ALS baseline (als3.py), float64 like the reference ----------------------
+ *      MangakiALS3.fit (als3.py:20-35) = tfr_als_set (init_vars, als3.py:57-65, drawn by the host
+ *      from np.random.rand) + tfr_als_load (bias = mean(y); per-user / per-work rating lists,
+ *      als3.py:36-55) + tfr_als_sweep (fit_user / fit_work for every user then every work,
+ *      als3.py:67-108); predict = tfr_als_predict at explicit pairs (als3.py:110-113).
+ *      nb_components <= 32.  Host pointers; calls synchronise. */
+typedef struct tfr_als tfr_als;
+int tfr_als_create(tfr_als** out, int64_t nb_users, int64_t nb_works, int32_t nb_components,
+                   double lambda_, int32_t device);
+int tfr_als_destroy(tfr_als* m);
+int tfr_als_set(tfr_als* m, const double* U, const double* V, const double* W_user, const double* W_work);
+int tfr_als_get(tfr_als* m, double* U, double* V, double* W_user, double* W_work, double* bias);
+int tfr_als_set_bias(tfr_als* m, double bias);
+int tfr_als_load(tfr_als* m, const int64_t* user_ids, const int64_t* work_ids, const double* y, int64_t n);
+int tfr_als_sweep(tfr_als* m, int32_t n_iterations, float* elapsed_ms /* may be NULL */);
+int tfr_als_predict(tfr_als* m, const int64_t* user_ids, const int64_t* work_ids, int64_t n, double* out);
+const char* tfr_als_last_error(void);
+
 /* ---- per-kernel timing with HIP events on the model's stream (bench.py roofline) -------- */
 enum {
     TFR_K_FORWARD = 0,        /* gather-dot forward (+ fused loss/grad when training)       */

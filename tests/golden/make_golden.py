@@ -16,6 +16,8 @@ What is a fixture here: inputs and expected outputs only (small .npz).
                            svd_train_val.py:15 sets it.  This is the one part of the path
                            whose parity is pinned by the reference's own code.
   5. fm_forward.npz        FM second-order forward on random CSR rows (binary and count-valued).
+  6. als_trajectory.npz    ALS fits produced by running the REAL reference class
+                           /root/reference/als3.py (numpy/scipy/sklearn only), np.random.seed(7).
 
 The SVD arithmetic (1-3) is "parity unpinned": TensorFlow is not installable here, so the
 expected values come from our float64 restatement (cross-checked against torch autograd in
@@ -200,6 +202,31 @@ def part5():
     np.savez_compressed(os.path.join(HERE, "fm_forward.npz"), **out)
 
 
+def part6():
+    """ALS trajectory from the REAL reference class (als3.py needs only numpy/scipy/sklearn)."""
+    import contextlib
+    import io
+    sys.path.insert(0, "/root/reference")
+    from als3 import MangakiALS3
+    out = {}
+    for name, (U, W, n, d, iters, lam) in {"small": (60, 45, 1500, 20, 3, 0.1), "d8": (120, 70, 4000, 8, 2, 0.05)}.items():
+        rs = np.random.RandomState(len(name))
+        X = np.stack([rs.randint(0, U, n), rs.randint(0, W, n)], 1)
+        y = rs.randint(0, 6, n).astype(np.float64)                    # includes exact zeros (als3.py:29)
+        Xt = np.stack([rs.randint(0, U, 300), rs.randint(0, W, 300)], 1)
+        yt = rs.randint(1, 6, 300).astype(np.float64)
+        als = MangakiALS3(nb_components=d, nb_iterations=iters, lambda_=lam)
+        als.nb_users, als.nb_works = U, W                             # set by the caller, forward.py:32-33
+        np.random.seed(7)
+        with contextlib.redirect_stdout(io.StringIO()):
+            als.fit(X, y, yt, Xt)
+        for k, v in dict(X=X, y=y, Xt=Xt, yt=yt, U=als.U, V=als.V, W_user=als.W_user, W_work=als.W_work,
+                         bias=np.array(als.bias), pred=als.predict(Xt), shape=np.array([U, W, d, iters]),
+                         lam=np.array(lam), rmse=np.array(als.compute_rmse(yt, als.predict(Xt)))).items():
+            out[name + "/" + k] = v
+    np.savez_compressed(os.path.join(HERE, "als_trajectory.npz"), **out)
+
+
 if __name__ == "__main__":
     part1()
     part2()
@@ -207,6 +234,7 @@ if __name__ == "__main__":
     part5()
     if os.path.isdir("/root/reference"):
         part4()
+        part6()
     else:
         print("note: /root/reference absent - iter_streams.npz not regenerated")
     for f in sorted(os.listdir(HERE)):

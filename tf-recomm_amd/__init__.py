@@ -10,5 +10,6 @@ from ._lib import TfrError, OutOfRangeError
 from .engine import SvdModel
 from . import dataio, graph, ops, config
 from .fm import FmModel
+from .als import MangakiALS3
 
-__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config", "FmModel"]
+__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config", "FmModel", "MangakiALS3"]

@@ -45,6 +45,7 @@ _p = C.c_void_p
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
 _f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
 
 # name -> (restype, argtypes).  Must list every symbol include/tfrecomm.h declares
 # (tests/test_abi.py parses the header and compares).
@@ -95,6 +96,15 @@ SIGNATURES = {
     "tfr_fm_forward_dev": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p]),
     "tfr_fm_sync": (C.c_int, [_p, _f32p]),
     "tfr_fm_last_error": (C.c_char_p, []),
+    "tfr_als_create": (C.c_int, [C.POINTER(_p), C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32]),
+    "tfr_als_destroy": (C.c_int, [_p]),
+    "tfr_als_set": (C.c_int, [_p, _f64p, _f64p, _f64p, _f64p]),
+    "tfr_als_get": (C.c_int, [_p, _f64p, _f64p, _f64p, _f64p, _f64p]),
+    "tfr_als_set_bias": (C.c_int, [_p, C.c_double]),
+    "tfr_als_load": (C.c_int, [_p, _i64p, _i64p, _f64p, C.c_int64]),
+    "tfr_als_sweep": (C.c_int, [_p, C.c_int32, _f32p]),
+    "tfr_als_predict": (C.c_int, [_p, _i64p, _i64p, C.c_int64, _f64p]),
+    "tfr_als_last_error": (C.c_char_p, []),
     "tfr_sort_segments": (C.c_int, [_p, C.c_int32, _i32p, C.c_int64, _i32p, _i32p]),
     "tfr_profile": (C.c_int, [_p, C.c_int32]),
     "tfr_profile_read": (C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), _i64p]),

@@ -1,0 +1,377 @@
+// als_kernels.hip - the ALS baseline of als3.py on the GPU, float64 like the reference.
+//   fit_user / fit_work (als3.py:67-108): for one user u with rated works J, ratings R:
+//       A = V[J]^T V[J] + lambda * N * I        b = (R - W_work[J] - (W_user[u] + bias)) . V[J]
+//       U[u] = solve(A, b)                      W_user[u] = mean(R - U[u].V[J]^T - W_work[J]) / (1 + lambda) - bias
+//   Inside one half-sweep every entity only reads the OTHER side's tables, so all users (then all
+//   works) are independent: one 256-thread block per entity builds the d x d normal equations from
+//   32-row tiles staged in LDS, factors them (Cholesky; A is SPD because of the lambda*N*I term) and
+//   back-substitutes.  Fixed summation order -> deterministic.  d <= 32.
+//   predict (als3.py:110-113) at explicit (user, work) pairs - the dense U V^T is never formed.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include <algorithm>
+#include "tfrecomm.h"
+
+namespace {
+
+constexpr int ALS_MAXD = 32;
+constexpr int ALS_TILE = 32;
+
+struct AlsFitArgs {
+    const int32_t* list; int64_t n_list;               // entities to fit
+    const int64_t* ptr; const int32_t* ids; const double* vals;   // their rating lists (other-side ids, ratings)
+    double* own; double* w_own; const double* other; const double* w_other;
+    double bias, lambda;
+    int32_t d;
+};
+
+__global__ __launch_bounds__(256) void k_als_fit(AlsFitArgs a) {
+    __shared__ double A[ALS_MAXD][ALS_MAXD + 1];
+    __shared__ double rows[ALS_TILE][ALS_MAXD + 1];
+    __shared__ double coef[ALS_TILE];
+    __shared__ double bvec[ALS_MAXD], xvec[ALS_MAXD];
+    __shared__ double red[256];
+    const int tid = threadIdx.x, d = a.d;
+    for (int64_t e = blockIdx.x; e < a.n_list; e += gridDim.x) {
+        const int32_t idx = a.list[e];
+        const int64_t lo = a.ptr[idx], hi = a.ptr[idx + 1];
+        const int64_t N = hi - lo;
+        const double b0 = a.w_own[idx] + a.bias;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};           // A entries t = tid + 256*q  (d*d <= 1024)
+        double accb = 0.0;                               // b entry tid (< d)
+        __syncthreads();
+        for (int64_t s = lo; s < hi; s += ALS_TILE) {
+            const int nk = (int)((hi - s < ALS_TILE) ? hi - s : ALS_TILE);
+            for (int t = tid; t < nk * d; t += 256) {
+                const int k = t / d, c = t % d;
+                rows[k][c] = a.other[(size_t)a.ids[s + k] * d + c];
+            }
+            if (tid < nk) coef[tid] = a.vals[s + tid] - a.w_other[a.ids[s + tid]] - b0;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = tid + 256 * q;
+                if (t < d * d) {
+                    const int r = t / d, c = t % d;
+                    double sacc = acc[q];
+                    for (int k = 0; k < nk; ++k) sacc += rows[k][r] * rows[k][c];
+                    acc[q] = sacc;
+                }
+            }
+            if (tid < d) {
+                double sb = accb;
+                for (int k = 0; k < nk; ++k) sb += coef[k] * rows[k][tid];
+                accb = sb;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = tid + 256 * q;
+            if (t < d * d) {
+                const int r = t / d, c = t % d;
+                A[r][c] = acc[q] + ((r == c) ? a.lambda * (double)N : 0.0);
+            }
+        }
+        if (tid < d) bvec[tid] = accb;
+        __syncthreads();
+        // Cholesky A = L L^T, in place (lower triangle), column by column
+        for (int j = 0; j < d; ++j) {
+            if (tid == 0) {
+                double s = A[j][j];
+                for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
+                A[j][j] = sqrt(s);
+            }
+            __syncthreads();
+            if (tid > j && tid < d) {
+                double s = A[tid][j];
+                for (int k = 0; k < j; ++k) s -= A[tid][k] * A[j][k];
+                A[tid][j] = s / A[j][j];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            for (int i = 0; i < d; ++i) {                 // L y = b
+                double s = bvec[i];
+                for (int k = 0; k < i; ++k) s -= A[i][k] * xvec[k];
+                xvec[i] = s / A[i][i];
+            }
+            for (int i = d - 1; i >= 0; --i) {            // L^T x = y
+                double s = xvec[i];
+                for (int k = i + 1; k < d; ++k) s -= A[k][i] * xvec[k];
+                xvec[i] = s / A[i][i];
+            }
+        }
+        __syncthreads();
+        if (tid < d) a.own[(size_t)idx * d + tid] = xvec[tid];
+        // W_own = mean(R - x.V[J] - W_other[J]) / (1 + lambda) - bias
+        double part = 0.0;
+        for (int64_t k = lo + tid; k < hi; k += 256) {
+            const int32_t j = a.ids[k];
+            const double* v = a.other + (size_t)j * d;
+            double dot = 0.0;
+            for (int c = 0; c < d; ++c) dot += xvec[c] * v[c];
+            part += a.vals[k] - dot - a.w_other[j];
+        }
+        red[tid] = part;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) a.w_own[idx] = red[0] / (double)N / (1.0 + a.lambda) - a.bias;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_als_predict(const double* U, const double* V, const double* Wu, const double* Ww,
+                                                     double bias, const int32_t* u, const int32_t* w, int64_t n, int d,
+                                                     double* out) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const double* pu = U + (size_t)u[k] * d;
+        const double* pv = V + (size_t)w[k] * d;
+        double s = 0.0;
+        for (int c = 0; c < d; ++c) s += pu[c] * pv[c];
+        out[k] = s + Wu[u[k]] + Ww[w[k]] + bias;
+    }
+}
+
+thread_local char g_als_err[512] = "";
+int als_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_als_err, sizeof(g_als_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define ALSCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return als_fail(e_ == hipErrorOutOfMemory ? TFR_ERR_NOMEM : TFR_ERR_HIP, \
+                                              "%s: %s", #expr, hipGetErrorString(e_));                \
+    } while (0)
+
+void als_free(void* p) { if (p) (void)hipFree(p); }
+
+}  // namespace
+
+struct tfr_als {
+    int64_t nu = 0, nw = 0, n = 0, n_users = 0, n_works = 0;
+    int32_t d = 0;
+    double lambda = 0.1, bias = 0.0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    double *U = nullptr, *V = nullptr, *Wu = nullptr, *Ww = nullptr;
+    int64_t *ptr_u = nullptr, *ptr_w = nullptr;
+    int32_t *ids_u = nullptr, *ids_w = nullptr, *users = nullptr, *works = nullptr;
+    double *val_u = nullptr, *val_w = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+const char* tfr_als_last_error(void) { return g_als_err; }
+
+int tfr_als_destroy(tfr_als* m) {
+    if (!m) return TFR_OK;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    void* ps[] = {m->U, m->V, m->Wu, m->Ww, m->ptr_u, m->ptr_w, m->ids_u, m->ids_w, m->users, m->works, m->val_u, m->val_w};
+    for (void* p : ps) als_free(p);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return TFR_OK;
+}
+
+int tfr_als_create(tfr_als** out, int64_t nb_users, int64_t nb_works, int32_t nb_components, double lambda_, int32_t device) {
+    if (!out) return als_fail(TFR_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (nb_users < 1 || nb_works < 1 || nb_users > 0x7fffffffLL || nb_works > 0x7fffffffLL || nb_components < 1 || nb_components > ALS_MAXD)
+        return als_fail(TFR_ERR_ARG, "need 1 <= nb_components <= %d and positive int32 table sizes", ALS_MAXD);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return als_fail(TFR_ERR_HIP, "no HIP device available - this library has no CPU path");
+    if (device < 0 || device >= ndev) return als_fail(TFR_ERR_ARG, "device %d not in [0,%d)", device, ndev);
+    ALSCHK(hipSetDevice(device));
+    tfr_als* m = new (std::nothrow) tfr_als();
+    if (!m) return als_fail(TFR_ERR_NOMEM, "host allocation failed");
+    m->nu = nb_users; m->nw = nb_works; m->d = nb_components; m->lambda = lambda_; m->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->U, (size_t)nb_users * m->d * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->V, (size_t)nb_works * m->d * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->Wu, (size_t)nb_users * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->Ww, (size_t)nb_works * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(m->U, 0, (size_t)nb_users * m->d * 8, m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->V, 0, (size_t)nb_works * m->d * 8, m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->Wu, 0, (size_t)nb_users * 8, m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->Ww, 0, (size_t)nb_works * 8, m->stream);
+    if (e == hipSuccess) e = hipEventCreate(&m->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&m->ev1);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) {
+        als_fail(e == hipErrorOutOfMemory ? TFR_ERR_NOMEM : TFR_ERR_HIP, "als_create: %s", hipGetErrorString(e));
+        char keep[512];
+        strncpy(keep, g_als_err, sizeof(keep));
+        tfr_als_destroy(m);
+        strncpy(g_als_err, keep, sizeof(g_als_err));
+        return e == hipErrorOutOfMemory ? TFR_ERR_NOMEM : TFR_ERR_HIP;
+    }
+    *out = m;
+    return TFR_OK;
+}
+
+int tfr_als_set(tfr_als* m, const double* U, const double* V, const double* W_user, const double* W_work) {
+    if (!m || !U || !V || !W_user || !W_work) return als_fail(TFR_ERR_ARG, "null argument");
+    ALSCHK(hipSetDevice(m->device));
+    ALSCHK(hipMemcpyAsync(m->U, U, (size_t)m->nu * m->d * 8, hipMemcpyHostToDevice, m->stream));
+    ALSCHK(hipMemcpyAsync(m->V, V, (size_t)m->nw * m->d * 8, hipMemcpyHostToDevice, m->stream));
+    ALSCHK(hipMemcpyAsync(m->Wu, W_user, (size_t)m->nu * 8, hipMemcpyHostToDevice, m->stream));
+    ALSCHK(hipMemcpyAsync(m->Ww, W_work, (size_t)m->nw * 8, hipMemcpyHostToDevice, m->stream));
+    ALSCHK(hipStreamSynchronize(m->stream));
+    return TFR_OK;
+}
+
+int tfr_als_get(tfr_als* m, double* U, double* V, double* W_user, double* W_work, double* bias) {
+    if (!m) return als_fail(TFR_ERR_ARG, "null model");
+    ALSCHK(hipSetDevice(m->device));
+    if (U) ALSCHK(hipMemcpyAsync(U, m->U, (size_t)m->nu * m->d * 8, hipMemcpyDeviceToHost, m->stream));
+    if (V) ALSCHK(hipMemcpyAsync(V, m->V, (size_t)m->nw * m->d * 8, hipMemcpyDeviceToHost, m->stream));
+    if (W_user) ALSCHK(hipMemcpyAsync(W_user, m->Wu, (size_t)m->nu * 8, hipMemcpyDeviceToHost, m->stream));
+    if (W_work) ALSCHK(hipMemcpyAsync(W_work, m->Ww, (size_t)m->nw * 8, hipMemcpyDeviceToHost, m->stream));
+    ALSCHK(hipStreamSynchronize(m->stream));
+    if (bias) *bias = m->bias;
+    return TFR_OK;
+}
+
+// X = (user_ids, work_ids), y: the training ratings (als3.py:20-29).  Builds the per-user and per-work
+// rating lists in insertion order (als3.py:36-55), bias = mean(y), and the sweep sets.
+int tfr_als_load(tfr_als* m, const int64_t* user_ids, const int64_t* work_ids, const double* y, int64_t n) {
+    if (!m || n < 1 || !user_ids || !work_ids || !y) return als_fail(TFR_ERR_ARG, "load: need n >= 1 and non-null columns");
+    ALSCHK(hipSetDevice(m->device));
+    for (int64_t k = 0; k < n; ++k)
+        if (user_ids[k] < 0 || user_ids[k] >= m->nu || work_ids[k] < 0 || work_ids[k] >= m->nw)
+            return als_fail(TFR_ERR_OOB, "rating %lld: id out of range", (long long)k);
+    double sum = 0.0;
+    for (int64_t k = 0; k < n; ++k) sum += y[k];
+    // numpy's mean uses pairwise summation; reproduce its value exactly enough by summing in long double
+    long double ls = 0.0L;
+    for (int64_t k = 0; k < n; ++k) ls += (long double)y[k];
+    (void)sum;
+    m->bias = (double)(ls / (long double)n);
+    auto build = [&](const int64_t* key, const int64_t* oth, int64_t rows, std::vector<int64_t>& ptr,
+                     std::vector<int32_t>& ids, std::vector<double>& vals, std::vector<int32_t>& list) {
+        ptr.assign((size_t)rows + 1, 0);
+        for (int64_t k = 0; k < n; ++k) ptr[(size_t)key[k] + 1]++;
+        for (int64_t r = 0; r < rows; ++r) ptr[(size_t)r + 1] += ptr[(size_t)r];
+        std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+        ids.resize((size_t)n); vals.resize((size_t)n);
+        std::vector<char> nz((size_t)rows, 0);
+        for (int64_t k = 0; k < n; ++k) {                 // stable: insertion order inside each list
+            const int64_t p = cur[(size_t)key[k]]++;
+            ids[(size_t)p] = (int32_t)oth[k];
+            vals[(size_t)p] = y[k];
+            if (y[k] != 0.0) nz[(size_t)key[k]] = 1;      // als3.py:29: entities with a non-zero rating
+        }
+        list.clear();
+        for (int64_t r = 0; r < rows; ++r) if (nz[(size_t)r]) list.push_back((int32_t)r);
+    };
+    std::vector<int64_t> pu, pw;
+    std::vector<int32_t> iu, iw, lu, lw;
+    std::vector<double> vu, vw;
+    build(user_ids, work_ids, m->nu, pu, iu, vu, lu);
+    build(work_ids, user_ids, m->nw, pw, iw, vw, lw);
+    ALSCHK(hipStreamSynchronize(m->stream));
+    void* old[] = {m->ptr_u, m->ptr_w, m->ids_u, m->ids_w, m->users, m->works, m->val_u, m->val_w};
+    for (void* p : old) als_free(p);
+    m->ptr_u = m->ptr_w = nullptr; m->ids_u = m->ids_w = m->users = m->works = nullptr; m->val_u = m->val_w = nullptr;
+    ALSCHK(hipMalloc((void**)&m->ptr_u, pu.size() * 8));
+    ALSCHK(hipMalloc((void**)&m->ptr_w, pw.size() * 8));
+    ALSCHK(hipMalloc((void**)&m->ids_u, (size_t)n * 4));
+    ALSCHK(hipMalloc((void**)&m->ids_w, (size_t)n * 4));
+    ALSCHK(hipMalloc((void**)&m->val_u, (size_t)n * 8));
+    ALSCHK(hipMalloc((void**)&m->val_w, (size_t)n * 8));
+    ALSCHK(hipMalloc((void**)&m->users, std::max<size_t>(1, lu.size()) * 4));
+    ALSCHK(hipMalloc((void**)&m->works, std::max<size_t>(1, lw.size()) * 4));
+    ALSCHK(hipMemcpy(m->ptr_u, pu.data(), pu.size() * 8, hipMemcpyHostToDevice));
+    ALSCHK(hipMemcpy(m->ptr_w, pw.data(), pw.size() * 8, hipMemcpyHostToDevice));
+    ALSCHK(hipMemcpy(m->ids_u, iu.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    ALSCHK(hipMemcpy(m->ids_w, iw.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    ALSCHK(hipMemcpy(m->val_u, vu.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    ALSCHK(hipMemcpy(m->val_w, vw.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    if (!lu.empty()) ALSCHK(hipMemcpy(m->users, lu.data(), lu.size() * 4, hipMemcpyHostToDevice));
+    if (!lw.empty()) ALSCHK(hipMemcpy(m->works, lw.data(), lw.size() * 4, hipMemcpyHostToDevice));
+    m->n = n; m->n_users = (int64_t)lu.size(); m->n_works = (int64_t)lw.size();
+    return TFR_OK;
+}
+
+int tfr_als_set_bias(tfr_als* m, double bias) {
+    if (!m) return als_fail(TFR_ERR_ARG, "null model");
+    m->bias = bias;
+    return TFR_OK;
+}
+
+// n_iterations x (every user, then every work) - the loop body of als3.py:30-35
+int tfr_als_sweep(tfr_als* m, int32_t n_iterations, float* elapsed_ms) {
+    if (!m || n_iterations < 0) return als_fail(TFR_ERR_ARG, "bad arguments");
+    if (!m->n) return als_fail(TFR_ERR_STATE, "no ratings: call tfr_als_load first");
+    ALSCHK(hipSetDevice(m->device));
+    (void)hipEventRecord(m->ev0, m->stream);
+    for (int it = 0; it < n_iterations; ++it) {
+        AlsFitArgs a;
+        a.bias = m->bias; a.lambda = m->lambda; a.d = m->d;
+        a.list = m->users; a.n_list = m->n_users; a.ptr = m->ptr_u; a.ids = m->ids_u; a.vals = m->val_u;
+        a.own = m->U; a.w_own = m->Wu; a.other = m->V; a.w_other = m->Ww;
+        if (a.n_list) hipLaunchKernelGGL(k_als_fit, dim3((unsigned)std::min<int64_t>(a.n_list, 65535)), dim3(256), 0, m->stream, a);
+        a.list = m->works; a.n_list = m->n_works; a.ptr = m->ptr_w; a.ids = m->ids_w; a.vals = m->val_w;
+        a.own = m->V; a.w_own = m->Ww; a.other = m->U; a.w_other = m->Wu;
+        if (a.n_list) hipLaunchKernelGGL(k_als_fit, dim3((unsigned)std::min<int64_t>(a.n_list, 65535)), dim3(256), 0, m->stream, a);
+    }
+    (void)hipEventRecord(m->ev1, m->stream);
+    ALSCHK(hipGetLastError());
+    ALSCHK(hipStreamSynchronize(m->stream));
+    if (elapsed_ms) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->ev0, m->ev1) != hipSuccess) ms = 0.f;
+        *elapsed_ms = ms;
+    }
+    return TFR_OK;
+}
+
+int tfr_als_predict(tfr_als* m, const int64_t* user_ids, const int64_t* work_ids, int64_t n, double* out) {
+    if (!m || n < 0 || (n > 0 && (!user_ids || !work_ids || !out))) return als_fail(TFR_ERR_ARG, "bad arguments");
+    if (n == 0) return TFR_OK;
+    ALSCHK(hipSetDevice(m->device));
+    std::vector<int32_t> u((size_t)n), w((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        if (user_ids[k] < 0 || user_ids[k] >= m->nu || work_ids[k] < 0 || work_ids[k] >= m->nw)
+            return als_fail(TFR_ERR_OOB, "pair %lld: id out of range", (long long)k);
+        u[(size_t)k] = (int32_t)user_ids[k];
+        w[(size_t)k] = (int32_t)work_ids[k];
+    }
+    int32_t *du = nullptr, *dw = nullptr;
+    double* dout = nullptr;
+    hipError_t e = hipMalloc((void**)&du, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dw, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(du, u.data(), (size_t)n * 4, hipMemcpyHostToDevice, m->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dw, w.data(), (size_t)n * 4, hipMemcpyHostToDevice, m->stream);
+    if (e == hipSuccess) {
+        int64_t nb = (n + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(k_als_predict, dim3((unsigned)nb), dim3(256), 0, m->stream, m->U, m->V, m->Wu, m->Ww, m->bias, du, dw, n,
+                           m->d, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    als_free(du); als_free(dw); als_free(dout);
+    if (e != hipSuccess) return als_fail(TFR_ERR_HIP, "als_predict: %s", hipGetErrorString(e));
+    return TFR_OK;
+}
+
+}  // extern "C"
