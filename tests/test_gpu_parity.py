@@ -425,3 +425,48 @@ def test_random_shapes_two_steps(case):
             run = 7.0 * B / max(1, min(U, I))
             assert_close(got[tid], orc.tables()[tid], rtol=4 * RTOL * max(1.0, np.sqrt(run / 64)),
                          what="table %s" % TABLE_NAMES[tid])
+
+
+# ------------------------------------------------------------------ full-size training step (C3-shaped)
+@pytest.mark.parametrize("opt,mode", [("adam", "lazy"), ("sgd", "tf1")])
+def test_train_step_large_against_compacted_oracle(opt, mode):
+    """BASELINE config 3 shape scaled to fit a test (D=128, B=262144, 2M x 200k rows, radix sort path,
+    fused in-place updates): the oracle runs on the compacted problem of the rows the batch touches,
+    which is exact for lazy Adam / SGD (untouched rows do not move - also checked)."""
+    U, I, D, B = 2_000_000, 200_000, 128, 262144
+    gen = np.random.default_rng(17)
+    P = gen.standard_normal((U, D), dtype=np.float32) * np.float32(0.05)
+    Q = gen.standard_normal((I, D), dtype=np.float32) * np.float32(0.05)
+    bu, bi = gen.standard_normal(U, dtype=np.float32) * np.float32(0.3), gen.standard_normal(I, dtype=np.float32) * np.float32(0.3)
+    rs = np.random.RandomState(17)
+    u = rs.randint(0, U, B).astype(np.int32)
+    i = np.where(rs.rand(B) < 0.3, rs.randint(0, 50, B), rs.randint(0, I, B)).astype(np.int32)   # 50 very hot items
+    r = rs.randint(1, 6, B).astype(np.float32)
+    kw = dict(optimizer=opt, adam_mode=mode, lr=2e-3, reg=0.03)
+    uu, ui = np.unique(u), np.unique(i)
+    orc = so.SvdOracle(uu.size, ui.size, D, dtype=np.float64, **kw)
+    orc.set_tables(0.2, bu[uu].astype(np.float64), bi[ui].astype(np.float64), P[uu].astype(np.float64), Q[ui].astype(np.float64))
+    cu, ci = np.searchsorted(uu, u), np.searchsorted(ui, i)
+    with T.SvdModel(U, I, D, **kw) as m:
+        m.set_tables(0.2, bu, bi, P, Q)
+        for s in range(2):
+            logits, lossv, regv = m.train_step(u, i, r)
+            wl, wloss, wreg = orc.train_step(cu, ci, r)
+            assert_close(logits, wl, rtol=2 * RTOL * (s + 1), what="logits")
+            assert_close(lossv, wloss, rtol=2 * RTOL * (s + 1), what="loss")
+            assert_close(regv, wreg, rtol=2 * RTOL * (s + 1), what="reg")
+        gP, gQ, gbu, gbi = m.get_table(L.P), m.get_table(L.Q), m.get_table(L.BU), m.get_table(L.BI)
+        gmu = float(m.get_table(L.MU))
+    run = 0.3 * B / 50                                               # a hot item's run length
+    # Adam's first steps move an element by ~lr * g / (0.03 |g| + eps): among 31 M elements a few
+    # have |g| ~ 1e-6, where fp32 rounding of g is amplified - SGD (same kernels) has no such term
+    base = (2e-4 if opt == "adam" else 4 * RTOL)
+    assert_close(gP[uu], orc.P, rtol=base, what="P")
+    assert_close(gQ[ui], orc.Q, rtol=base * np.sqrt(run / 64), what="Q")
+    assert_close(gbu[uu], orc.bu, rtol=base, what="bu")
+    assert_close(gbi[ui], orc.bi, rtol=base * np.sqrt(run / 64), what="bi")
+    assert abs(gmu - float(orc.mu)) <= 1e-4 * max(1.0, abs(float(orc.mu)))
+    mask = np.ones(U, bool); mask[uu] = False
+    assert np.array_equal(gP[mask], P[mask]) and np.array_equal(gbu[mask], bu[mask])      # untouched rows never move
+    mask = np.ones(I, bool); mask[ui] = False
+    assert np.array_equal(gQ[mask], Q[mask])
