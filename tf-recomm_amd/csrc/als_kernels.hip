@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int ALS_MAXD = 32;
-constexpr int ALS_TILE = 32;
+constexpr int ALS_TILE = 32;         // ratings staged per LDS tile (128 measured no faster: not latency-bound)
 
 struct AlsFitArgs {
     const int32_t* list; int64_t n_list;               // entities to fit

@@ -531,6 +531,7 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
         a.ids = d_store_ids; a.store = m->store;
         a.u_out = m->d_u; a.it_out = m->d_i;
     }
+    { static int lr = -1; if (lr < 0) { const char* e = getenv("TFR_LDS_REDUCE"); lr = (e && e[0] == '1') ? 1 : 0; } a.lds_reduce = lr; }
     a.D = m->D; a.loss = m->o.loss; a.item_abs = m->o.item_abs; a.reg_bias = m->o.reg_bias;
     const int grid = forward_grid(B, m->G, mode);
     if (nblk_out) *nblk_out = grid;

@@ -21,7 +21,7 @@ struct FwdArgs {
     int32_t* u_out; int32_t* it_out;
     float* logits; float* g; float* partials; int32_t* err;
     int64_t B, U, I, N;
-    int32_t D, loss, item_abs, reg_bias;
+    int32_t D, loss, item_abs, reg_bias, lds_reduce;
 };
 
 struct GatherArgs {

@@ -61,6 +61,23 @@ __device__ __forceinline__ float group_sum(float x) {
     return x;
 }
 
+// The same reduction staged through LDS memory instead of the cross-lane network: every lane
+// parks its partial in LDS, the group's first lane reads the G values back as 16-byte vectors and
+// adds them in lane order.  Kept for the A/B recorded in DESIGN.md (the butterfly is the default).
+template <int G>
+__device__ __forceinline__ float group_sum_lds(float x, float* wave_slot /* 64 floats of this wave */, int lane) {
+    wave_slot[lane] = x;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own LDS writes have landed
+    const int g0 = lane & ~(G - 1);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < G; q += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(wave_slot + g0 + q);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    return s;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) x += __shfl_down(x, o, 64);
@@ -185,7 +202,12 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
                 s = fmaf(p[j].v[e], a.item_abs ? fabsf(qv) : qv, s);
                 if constexpr (MODE == MODE_TRAIN) sq = fmaf(p[j].v[e], p[j].v[e], fmaf(qv, qv, sq));
             }
-            s = group_sum<G>(s);
+            if (a.lds_reduce) {
+                __shared__ float stage[NW][64];
+                s = group_sum_lds<G>(s, stage[threadIdx.x >> 6], lane);
+            } else {
+                s = group_sum<G>(s);
+            }
             const float logit = ((s + mu) + bu_[j]) + bi_[j];      // ops.py:45-47 order
             if (gl == 0 && ok[j]) {
                 if constexpr (MODE == MODE_INFER) {
