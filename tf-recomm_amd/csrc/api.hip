@@ -606,6 +606,68 @@ static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int6
 
 static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t B);
 
+// forward (+ fused store gather) and the stable sort of both id columns for one minibatch; K4
+// (`f`) rides in the csort scan launch when that path is taken (fin_done).  du/di are updated
+// to where the batch ids live afterwards.
+static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, const float* dr, int64_t B,
+                          float* d_logits, const int64_t* d_store_ids, FinArgs& f, int& nblk, bool& fin_done) {
+    const tfr_opts& o = m->o;
+    hipStream_t s = m->stream;
+    int rc;
+    if (d_store_ids && B >= 32768) {
+        // big batches are bandwidth-bound: a separate gather keeps the forward's dependent chain
+        // at ids -> rows; small batches are launch-bound and gather inside the forward instead
+        if ((rc = gather_batch(m, d_store_ids, 0, B))) return rc;
+        d_store_ids = nullptr;
+        du = m->d_u; di = m->d_i; dr = m->d_r;
+    }
+    if (m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i)) {
+        // small tables: forward and the counting sort's rank pass share one launch, then
+        // scan (+K4) and scatter
+        FrontArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        FwdArgs& fw = fa.f;
+        fw.P = m->w[TFR_P]; fw.Q = m->w[TFR_Q]; fw.bu = m->w[TFR_BU]; fw.bi = m->w[TFR_BI]; fw.mu = m->w[TFR_MU];
+        fw.u = du; fw.it = di; fw.r = dr;
+        fw.logits = d_logits; fw.g = m->d_g; fw.partials = m->partials; fw.err = m->d_err;
+        fw.B = B; fw.U = m->U; fw.I = m->I; fw.N = m->N;
+        fw.D = m->D; fw.loss = o.loss; fw.item_abs = o.item_abs; fw.reg_bias = o.reg_bias;
+        if (d_store_ids) { fw.ids = d_store_ids; fw.store = m->store; }     // rank blocks publish the ids
+        CSortArgs& c = fa.c;
+        c.keys[0] = d_store_ids ? m->d_u : du; c.keys[1] = d_store_ids ? m->d_i : di;
+        c.ks[0] = m->ks_u; c.ks[1] = m->ks_i; c.ps[0] = m->ps_u; c.ps[1] = m->ps_i;
+        c.lrank[0] = m->lrank_u; c.lrank[1] = m->lrank_i; c.hist[0] = m->hist_u; c.hist[1] = m->hist_i;
+        c.offs[0] = m->offs_u; c.offs[1] = m->offs_i; c.binbase[0] = m->binbase_u; c.binbase[1] = m->binbase_i;
+        c.blocktot[0] = m->blocktot_u; c.blocktot[1] = m->blocktot_i;
+        c.nbins[0] = 1 << m->bits_u; c.nbins[1] = 1 << m->bits_i;
+        c.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+        c.B = B;
+        fa.key_out[0] = m->d_u; fa.key_out[1] = m->d_i;
+        fa.nfwd = front_forward_blocks(B, m->G);
+        nblk = fa.nfwd;
+        {
+            Prof p(m, TFR_K_FORWARD);
+            launch_front(fa, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        if (d_store_ids) { du = m->d_u; di = m->d_i; }
+        f.nblk = nblk;
+        {
+            Prof p(m, TFR_K_SORT);
+            launch_csort_tail(c, &f, s);
+        }
+        HIPCHK(hipGetLastError());
+        fin_done = true;
+    } else {
+        rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk, d_store_ids);
+        if (rc) return rc;
+        if (d_store_ids) { du = m->d_u; di = m->d_i; }
+        f.nblk = nblk;
+        if ((rc = sort_columns(m, du, di, B, &f, &fin_done))) return rc;
+    }
+    return TFR_OK;
+}
+
 // one minibatch on device-resident (u, i, r) - or, with d_store_ids, on rows of the resident
 // store gathered inside the forward kernel; out3 = optional device {loss, reg, sum_g} slot
 static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
@@ -626,57 +688,7 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
     if (B > 0) {
         int rc;
-        if (d_store_ids && B >= 32768) {
-            // big batches are bandwidth-bound: a separate gather keeps the forward's dependent chain
-            // at ids -> rows; small batches are launch-bound and gather inside the forward instead
-            if ((rc = gather_batch(m, d_store_ids, 0, B))) return rc;
-            d_store_ids = nullptr;
-            du = m->d_u; di = m->d_i; dr = m->d_r;
-        }
-        if (m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i)) {
-            // small tables: forward and the counting sort's rank pass share one launch, then
-            // scan (+K4) and scatter
-            FrontArgs fa;
-            memset(&fa, 0, sizeof(fa));
-            FwdArgs& fw = fa.f;
-            fw.P = m->w[TFR_P]; fw.Q = m->w[TFR_Q]; fw.bu = m->w[TFR_BU]; fw.bi = m->w[TFR_BI]; fw.mu = m->w[TFR_MU];
-            fw.u = du; fw.it = di; fw.r = dr;
-            fw.logits = d_logits; fw.g = m->d_g; fw.partials = m->partials; fw.err = m->d_err;
-            fw.B = B; fw.U = m->U; fw.I = m->I; fw.N = m->N;
-            fw.D = m->D; fw.loss = o.loss; fw.item_abs = o.item_abs; fw.reg_bias = o.reg_bias;
-            if (d_store_ids) { fw.ids = d_store_ids; fw.store = m->store; }     // rank blocks publish the ids
-            CSortArgs& c = fa.c;
-            c.keys[0] = d_store_ids ? m->d_u : du; c.keys[1] = d_store_ids ? m->d_i : di;
-            c.ks[0] = m->ks_u; c.ks[1] = m->ks_i; c.ps[0] = m->ps_u; c.ps[1] = m->ps_i;
-            c.lrank[0] = m->lrank_u; c.lrank[1] = m->lrank_i; c.hist[0] = m->hist_u; c.hist[1] = m->hist_i;
-            c.offs[0] = m->offs_u; c.offs[1] = m->offs_i; c.binbase[0] = m->binbase_u; c.binbase[1] = m->binbase_i;
-            c.blocktot[0] = m->blocktot_u; c.blocktot[1] = m->blocktot_i;
-            c.nbins[0] = 1 << m->bits_u; c.nbins[1] = 1 << m->bits_i;
-            c.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
-            c.B = B;
-            fa.key_out[0] = m->d_u; fa.key_out[1] = m->d_i;
-            fa.nfwd = front_forward_blocks(B, m->G);
-            nblk = fa.nfwd;
-            {
-                Prof p(m, TFR_K_FORWARD);
-                launch_front(fa, m->G, m->VEC, s);
-            }
-            HIPCHK(hipGetLastError());
-            if (d_store_ids) { du = m->d_u; di = m->d_i; }
-            f.nblk = nblk;
-            {
-                Prof p(m, TFR_K_SORT);
-                launch_csort_tail(c, &f, s);
-            }
-            HIPCHK(hipGetLastError());
-            fin_done = true;
-        } else {
-            rc = run_forward(m, MODE_TRAIN, du, di, dr, B, d_logits, m->d_g, &nblk, d_store_ids);
-            if (rc) return rc;
-            if (d_store_ids) { du = m->d_u; di = m->d_i; }
-            f.nblk = nblk;
-            if ((rc = sort_columns(m, du, di, B, &f, &fin_done))) return rc;
-        }
+        if ((rc = front_and_sort(m, du, di, dr, B, d_logits, d_store_ids, f, nblk, fin_done))) return rc;
         RedArgs r;
         memset(&r, 0, sizeof(r));
         r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
@@ -1366,31 +1378,36 @@ int tfr_dp_local_grads(tfr_model* m, const int32_t* du, const int32_t* di, const
     float* tail = gbi + m->I;
     hipStream_t s = m->stream;
     int nblk = 0;
+    bool fin_done = false;
+    FinArgs f;                         // local {loss, reg, sum g} -> tail of the flat buffer; no mu update yet
+    memset(&f, 0, sizeof(f));
+    f.partials = m->partials; f.scalars = m->scalars; f.out = tail; f.err = m->d_err;
+    f.mu = m->w[TFR_MU];
     if (B > 0) {
-        if ((rc = run_forward(m, MODE_TRAIN, du, di, dr, B, nullptr, m->d_g, &nblk, d_store_ids))) return rc;
-        if (d_store_ids) { du = m->d_u; di = m->d_i; }
-        if ((rc = sort_columns(m, du, di, B))) return rc;
+        if ((rc = front_and_sort(m, du, di, dr, B, nullptr, d_store_ids, f, nblk, fin_done))) return rc;
         RedArgs r;
         memset(&r, 0, sizeof(r));
         r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
         r.item_abs = o.item_abs; r.reg_bias = o.reg_bias; r.lam = o.reg;
         RedPair pr;
-        pr.a[0] = r;
+        pr.a[0] = r;                   // whole runs go straight to their row of the flat buffer
         pr.a[0].side = 1; pr.a[0].ks = m->ks_i; pr.a[0].ps = m->ps_i; pr.a[0].other = du;
         pr.a[0].own = m->w[TFR_Q]; pr.a[0].partner = m->w[TFR_P]; pr.a[0].own_bias = m->w[TFR_BI];
         pr.a[0].grad_rows = m->gq; pr.a[0].grad_bias = m->gbq;
+        pr.a[0].dense_rows = gQ; pr.a[0].dense_bias = gbi;
         pr.a[1] = r;
         pr.a[1].side = 0; pr.a[1].ks = m->ks_u; pr.a[1].ps = m->ps_u; pr.a[1].other = di;
         pr.a[1].own = m->w[TFR_P]; pr.a[1].partner = m->w[TFR_Q]; pr.a[1].own_bias = m->w[TFR_BU];
         pr.a[1].grad_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D; pr.a[1].grad_bias = m->gbp;
+        pr.a[1].dense_rows = gP; pr.a[1].dense_bias = gbu;
         {
             Prof p(m, TFR_K_REDUCE_ITEM);
             launch_seg_reduce(pr, 2, RMODE_SCRATCH, m->G, m->VEC, s);
         }
         HIPCHK(hipGetLastError());
-        ApplyPair app;
+        ApplyPair app;                 // runs split over several reduce blocks: add their pieces, emit the row
         memset(&app, 0, sizeof(app));
-        app.a[0].err = m->d_err; app.a[0].B = B; app.a[0].D = m->D;
+        app.a[0].err = m->d_err; app.a[0].B = B; app.a[0].D = m->D; app.a[0].only_split = 1;
         app.a[0].ks = m->ks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
         app.a[0].w = gQ; app.a[0].bias_w = gbi;
         app.a[1] = app.a[0];
@@ -1398,15 +1415,12 @@ int tfr_dp_local_grads(tfr_model* m, const int32_t* du, const int32_t* di, const
         app.a[1].w = gP; app.a[1].bias_w = gbu;
         {
             Prof p(m, TFR_K_APPLY);
-            launch_apply_rows(app, 2, 2, m->G, m->VEC, s);      // emit the reduced rows into the dense buffers
+            launch_apply_rows(app, 2, 2, m->G, m->VEC, s);
         }
         HIPCHK(hipGetLastError());
     }
-    FinArgs f;
-    memset(&f, 0, sizeof(f));
-    f.partials = m->partials; f.nblk = nblk; f.scalars = m->scalars; f.out = tail; f.err = m->d_err;
-    f.mu = m->w[TFR_MU];
-    {
+    if (!fin_done) {
+        f.nblk = nblk;
         Prof p(m, TFR_K_FINALIZE);
         launch_finalize(f, s);
     }
