@@ -55,7 +55,7 @@ struct tfr_model {
     int64_t cap = 0;
     int32_t *d_u = nullptr, *d_i = nullptr;
     float *d_r = nullptr, *d_logits = nullptr, *d_g = nullptr;
-    int32_t *iota = nullptr, *ks_u = nullptr, *ps_u = nullptr, *ks_i = nullptr, *ps_i = nullptr;
+    int32_t *ks_u = nullptr, *ps_u = nullptr, *ks_i = nullptr, *ps_i = nullptr;
     int32_t *ks2_u = nullptr, *ps2_u = nullptr, *ks2_i = nullptr, *ps2_i = nullptr;   // rsort ping-pong
     int32_t *lrank_u = nullptr, *lrank_i = nullptr, *hist_u = nullptr, *hist_i = nullptr;   // csort
     int32_t *offs_u = nullptr, *offs_i = nullptr, *binbase_u = nullptr, *binbase_i = nullptr;
@@ -143,7 +143,7 @@ static int drain_profile(tfr_model* m) {
 
 static void free_workspace(tfr_model* m) {
     dfree(m->d_u); dfree(m->d_i); dfree(m->d_r); dfree(m->d_logits); dfree(m->d_g);
-    dfree(m->iota); dfree(m->ks_u); dfree(m->ps_u); dfree(m->ks_i); dfree(m->ps_i);
+    dfree(m->ks_u); dfree(m->ps_u); dfree(m->ks_i); dfree(m->ps_i);
     dfree(m->ks2_u); dfree(m->ps2_u); dfree(m->ks2_i); dfree(m->ps2_i); dfree(m->gq); dfree(m->gp); dfree(m->gbq); dfree(m->gbp);
     dfree(m->partials); dfree(m->lrank_u); dfree(m->lrank_i); dfree(m->hist_u); dfree(m->hist_i);
     dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
@@ -152,7 +152,7 @@ static void free_workspace(tfr_model* m) {
     m->lrank_u = m->lrank_i = m->hist_u = m->hist_i = nullptr;
     m->offs_u = m->offs_i = m->binbase_u = m->binbase_i = nullptr;
     m->d_u = m->d_i = nullptr; m->d_r = m->d_logits = m->d_g = nullptr;
-    m->iota = m->ks_u = m->ps_u = m->ks_i = m->ps_i = nullptr;
+    m->ks_u = m->ps_u = m->ks_i = m->ps_i = nullptr;
     m->ks2_u = m->ps2_u = m->ks2_i = m->ps2_i = nullptr; m->gq = m->gp = m->gbq = m->gbp = nullptr; m->partials = nullptr;
     m->cap = 0;
 }
@@ -170,7 +170,6 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     if ((rc = dmalloc(&m->d_r, cap))) return rc;
     if ((rc = dmalloc(&m->d_logits, cap))) return rc;
     if ((rc = dmalloc(&m->d_g, cap))) return rc;
-    if ((rc = dmalloc(&m->iota, cap))) return rc;
     if ((rc = dmalloc(&m->ks_u, cap))) return rc;
     if ((rc = dmalloc(&m->ps_u, cap))) return rc;
     if ((rc = dmalloc(&m->ks_i, cap))) return rc;
@@ -204,8 +203,6 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
         if ((rc = dmalloc(&m->blocktot_i, 64 + 256 * ntiles / 4096))) return rc;
         m->csort_ok = small;
     }
-    launch_iota(m->iota, cap, m->stream);
-    HIPCHK(hipGetLastError());
     m->cap = cap;
     return TFR_OK;
 }

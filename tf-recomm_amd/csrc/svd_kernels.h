@@ -138,7 +138,6 @@ void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipSt
 void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s);
 void launch_gather(const GatherArgs& a, hipStream_t s);
 void launch_gather_rows(const GatherRowsArgs& a, int G, int VEC, hipStream_t s);
-void launch_iota(int32_t* p, int64_t n, hipStream_t s);
 void launch_pack_triples(const int32_t* u, const int32_t* it, const float* r, void* store, int64_t n, hipStream_t s);
 void launch_finalize(const FinArgs& a, hipStream_t s);
 void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s);

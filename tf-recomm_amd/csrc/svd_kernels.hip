@@ -347,12 +347,6 @@ __global__ __launch_bounds__(256) void k_pack_triples(const int32_t* u, const in
         store[k] = make_int4(u[k], it[k], __float_as_int(r[k]), 0);
 }
 
-__global__ __launch_bounds__(256) void k_iota(int32_t* p, int64_t n) {
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
-         k += (int64_t)gridDim.x * blockDim.x)
-        p[k] = (int32_t)k;
-}
-
 // ------------------------------------------------------------------------------------
 // Optimiser arithmetic, written in the operation order of the TF kernels they restate.
 struct AdamC { float alpha, b1, b2, eps, omb1, omb2; };
@@ -896,10 +890,6 @@ void launch_gather(const GatherArgs& a, hipStream_t s) {
 
 void launch_pack_triples(const int32_t* u, const int32_t* it, const float* r, void* store, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_triples, dim3(flat_grid(n)), dim3(256), 0, s, u, it, r, reinterpret_cast<int4*>(store), n);
-}
-
-void launch_iota(int32_t* p, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_iota, dim3(flat_grid(n)), dim3(256), 0, s, p, n);
 }
 
 void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s) {
