@@ -136,7 +136,7 @@ def time_cpu_baseline(wl, train, ids, budget_s=12.0):
                        "scalar restatement of the svd_train_val.py step (TensorFlow unavailable)" % (nsteps, el))
 
 
-def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, D=128, B=262144, sequential=False):
+def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, D=128, B=262144, sequential=False, zipf=0.0):
     """BASELINE configs[2] shape, forward only: achieved algorithmic GB/s of the gather-dot."""
     import tfrecomm_amd as T
     import torch
@@ -147,6 +147,13 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
     nb = 8
     du = torch.randint(0, U, (nb, B), dtype=torch.int32, device="cuda", generator=g)
     di = torch.randint(0, I, (nb, B), dtype=torch.int32, device="cuda", generator=g)
+    if zipf > 0:        # popularity-skewed items: rank k drawn with probability ~ k^-a (host, seeded), rank -> random row
+        rs = np.random.RandomState(13575)
+        w = 1.0 / np.arange(1, I + 1, dtype=np.float64) ** zipf
+        cdf = np.cumsum(w / w.sum())
+        ranks = np.searchsorted(cdf, rs.rand(nb * B)).clip(0, I - 1)
+        perm = rs.permutation(I)
+        di = torch.from_numpy(perm[ranks].astype(np.int32).reshape(nb, B)).to("cuda")
     if sequential:      # diagnostic: perfectly streaming rows
         du = (torch.arange(nb * B, device="cuda", dtype=torch.int64) % U).to(torch.int32).reshape(nb, B).contiguous()
         di = (torch.arange(nb * B, device="cuda", dtype=torch.int64) % I).to(torch.int32).reshape(nb, B).contiguous()
@@ -180,9 +187,11 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
     torch.cuda.synchronize()
     copy_gbs = 2 * x.numel() * 4 / (min(ev[i].elapsed_time(ev[i + 1]) for i in range(10)) * 1e-3) / 1e9
     del x, y
-    return dict(checksum=chk, kernel="k_forward<32,4,infer>", workload="10M users x 1M items, dim=128, batch=262144, uniform ids",
+    return dict(checksum=chk, kernel="k_forward<%d,4,infer>" % max(4, D // 4),
+                workload="%d users x %d items, dim=%d, batch=%d, %s ids" % (U, I, D, B, "Zipf(%.2f) item" % zipf if zipf > 0 else
+                                                                          ("sequential" if sequential else "uniform")),
                 bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                traffic=profiled_traffic("k_forward<32, 4, 0") if (U, I, D, B) == (10_000_000, 1_000_000, 128, 262144) else None,
+                traffic=profiled_traffic("k_forward<32, 4, 0") if (U, I, D, B, zipf) == (10_000_000, 1_000_000, 128, 262144, 0.0) else None,
                 traffic_source="profiles/r01_pmc_summary.csv (rocprofv3 --pmc, separate passes)",
                 algorithmic_bytes_per_launch=per_launch, avg_launch_us=ms / n * 1e3,
                 ratings_per_s=B * n / (ms * 1e-3), wall_ratings_per_s=B * steps / wall,
@@ -289,6 +298,7 @@ def main():
     ap.add_argument("--ns-batch", type=int, default=262144)
     ap.add_argument("--ns-dim", type=int, default=128)
     ap.add_argument("--ns-sequential", action="store_true")
+    ap.add_argument("--ns-zipf", type=float, default=0.0, help="item ids ~ Zipf(a) instead of uniform (SURVEY 8d)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -321,7 +331,7 @@ def main():
         return
     if args.only_north_star:
         print(json.dumps(north_star_forward(local_rank, steps=args.steps, warmup=args.warmup, U=args.ns_users,
-                                            I=args.ns_items, B=args.ns_batch, D=args.ns_dim, sequential=args.ns_sequential)), flush=True)
+                                            I=args.ns_items, B=args.ns_batch, D=args.ns_dim, sequential=args.ns_sequential, zipf=args.ns_zipf)), flush=True)
         return
     wl = dict(WORKLOADS[args.workload])
     if args.adam_mode:
@@ -409,7 +419,8 @@ def main():
                            parallelism="single GPU"),
                val_rmse=val_rmse, roofline=roofline)
     if not args.no_north_star:
-        out["north_star_forward"] = north_star_forward(local_rank)
+        out["north_star_forward"] = north_star_forward(local_rank)                      # uniform ids: worst case for caches
+        out["north_star_forward_zipf"] = north_star_forward(local_rank, zipf=1.05)      # reported separately
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = time_cpu_baseline(wl, train, ids[W:W + 64])
     out["reference_readme"] = dict(note="README.md:63 batch=10000: 1.1 s/epoch ~ 8.2e5 ratings/s (derived, dim and "
