@@ -470,3 +470,32 @@ def test_train_step_large_against_compacted_oracle(opt, mode):
     assert np.array_equal(gP[mask], P[mask]) and np.array_equal(gbu[mask], bu[mask])      # untouched rows never move
     mask = np.ones(I, bool); mask[ui] = False
     assert np.array_equal(gQ[mask], Q[mask])
+
+
+# ------------------------------------------------------------------ BASELINE config 3 at its true size
+def test_config3_full_size_properties():
+    """10M users x 1M items, dim=128, batch=262144 (5.6 GB of tables + 11 GB of Adam state, initialised
+    on the device): properties that do not need an oracle at this size."""
+    U, I, D, B = 10_000_000, 1_000_000, 128, 262144
+    rs = np.random.RandomState(33)
+    batches = [(rs.randint(0, U, B).astype(np.int32), rs.randint(0, I, B).astype(np.int32),
+                rs.randint(1, 6, B).astype(np.float32)) for _ in range(3)]
+    probe_u, probe_i = rs.randint(0, U, 100000).astype(np.int32), rs.randint(0, I, 100000).astype(np.int32)
+    # make the probe overlap rows the batches touch, so it sees the updates
+    probe_u[:50000], probe_i[:50000] = batches[0][0][:50000], batches[1][1][:50000]
+    runs = []
+    for rep in range(2):
+        with T.SvdModel(U, I, D, optimizer="adam", adam_mode="lazy", lr=5e-3, reg=0.02) as m:
+            m.init_tables(seed=5)
+            if rep == 0:
+                a = m.forward(batches[0][0], batches[0][1])
+                perm = rs.permutation(B)
+                assert np.array_equal(a[perm], m.forward(batches[0][0][perm], batches[0][1][perm]))
+                assert np.isfinite(a).all() and a.std() > 0.5           # biases ~ N(0,1) truncated
+            losses = [m.train_step(*b, want_logits=False)[1] for b in batches]
+            rep_losses = [m.train_step(*batches[0], want_logits=False)[1] for _ in range(4)]
+            runs.append((losses, rep_losses, m.forward(probe_u, probe_i), m.step))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]          # bit-identical trajectory
+    assert np.array_equal(runs[0][2], runs[1][2])
+    assert runs[0][3] == 7
+    assert runs[0][1][-1] < runs[0][1][0] < runs[0][0][0]                 # repeated batch: loss falls
