@@ -606,8 +606,13 @@ static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t 
 // forward (+ fused store gather) and the stable sort of both id columns for one minibatch; K4
 // (`f`) rides in the csort scan launch when that path is taken (fin_done).  du/di are updated
 // to where the batch ids live afterwards.
+static bool tiles_eligible(const tfr_model* m, int64_t B) {
+    return B > 0 && m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i) && (B + CSORT_TILE - 1) / CSORT_TILE <= 16;
+}
+
 static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, const float* dr, int64_t B,
-                          float* d_logits, const int64_t* d_store_ids, FinArgs& f, int& nblk, bool& fin_done) {
+                          float* d_logits, const int64_t* d_store_ids, FinArgs& f, int& nblk, bool& fin_done,
+                          bool tiles = false) {
     const tfr_opts& o = m->o;
     hipStream_t s = m->stream;
     int rc;
@@ -641,6 +646,7 @@ static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, 
         c.B = B;
         fa.key_out[0] = m->d_u; fa.key_out[1] = m->d_i;
         fa.nfwd = front_forward_blocks(B, m->G);
+        fa.tile_local = tiles ? 1 : 0;
         nblk = fa.nfwd;
         {
             Prof p(m, TFR_K_FORWARD);
@@ -649,6 +655,7 @@ static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, 
         HIPCHK(hipGetLastError());
         if (d_store_ids) { du = m->d_u; di = m->d_i; }
         f.nblk = nblk;
+        if (tiles) return TFR_OK;      // tile-local order is final; K4 rides in the sweep launch
         {
             Prof p(m, TFR_K_SORT);
             launch_csort_tail(c, &f, s);
@@ -676,7 +683,7 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
     int nblk = 0;
     hipStream_t s = m->stream;
-    bool fin_done = false;
+    bool fin_done = false, tiles = false;
     FinArgs f;
     memset(&f, 0, sizeof(f));
     f.partials = m->partials; f.scalars = m->scalars; f.out = out3;
@@ -685,7 +692,56 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
     if (B > 0) {
         int rc;
-        if ((rc = front_and_sort(m, du, di, dr, B, d_logits, d_store_ids, f, nblk, fin_done))) return rc;
+        tiles = tiles_eligible(m, B);
+        if ((rc = front_and_sort(m, du, di, dr, B, d_logits, d_store_ids, f, nblk, fin_done, tiles))) return rc;
+        if (tiles) {
+            // small tables: per-tile sorted order -> piece sums per tile -> one sweep that combines a
+            // row's per-tile partials, applies the optimiser to both tables and runs K4
+            RedArgs r;
+            memset(&r, 0, sizeof(r));
+            r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D; r.tile = CSORT_TILE;
+            r.item_abs = o.item_abs; r.reg_bias = o.reg_bias; r.lam = o.reg;
+            RedPair pr;
+            pr.a[0] = r;
+            pr.a[0].side = 1; pr.a[0].ks = m->ks_i; pr.a[0].ps = m->ps_i; pr.a[0].other = du;
+            pr.a[0].own = m->w[TFR_Q]; pr.a[0].partner = m->w[TFR_P]; pr.a[0].own_bias = m->w[TFR_BI];
+            pr.a[0].grad_rows = m->gq; pr.a[0].grad_bias = m->gbq;
+            pr.a[1] = r;
+            pr.a[1].side = 0; pr.a[1].ks = m->ks_u; pr.a[1].ps = m->ps_u; pr.a[1].other = di;
+            pr.a[1].own = m->w[TFR_P]; pr.a[1].partner = m->w[TFR_Q]; pr.a[1].own_bias = m->w[TFR_BU];
+            pr.a[1].grad_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D; pr.a[1].grad_bias = m->gbp;
+            {
+                Prof p(m, TFR_K_REDUCE_ITEM);
+                launch_seg_reduce(pr, 2, RMODE_SCRATCH, m->G, m->VEC, s);
+            }
+            HIPCHK(hipGetLastError());
+            TileDenseLaunch L;
+            memset(&L, 0, sizeof(L));
+            TileDenseArgs d;
+            memset(&d, 0, sizeof(d));
+            d.err = m->d_err; d.D = m->D; d.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+            d.opt = adam ? 0 : 1; d.skip_untouched = tf1 ? 0 : 1;
+            d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps; d.lr = o.lr;
+            L.a[0] = d;                // items
+            L.a[0].tab = m->hist_i; L.a[0].nbins = 1 << m->bits_i; L.a[0].rows = m->I;
+            L.a[0].grad_rows = m->gq; L.a[0].grad_bias = m->gbq;
+            L.a[0].w = m->w[TFR_Q]; L.a[0].m = m->m[TFR_Q]; L.a[0].v = m->v[TFR_Q];
+            L.a[0].bias_w = m->w[TFR_BI]; L.a[0].bias_m = m->m[TFR_BI]; L.a[0].bias_v = m->v[TFR_BI];
+            L.a[0].frozen_rows = (m->frozen >> TFR_Q) & 1; L.a[0].frozen_bias = (m->frozen >> TFR_BI) & 1;
+            L.a[1] = d;                // users
+            L.a[1].tab = m->hist_u; L.a[1].nbins = 1 << m->bits_u; L.a[1].rows = m->U;
+            L.a[1].grad_rows = pr.a[1].grad_rows; L.a[1].grad_bias = m->gbp;
+            L.a[1].w = m->w[TFR_P]; L.a[1].m = m->m[TFR_P]; L.a[1].v = m->v[TFR_P];
+            L.a[1].bias_w = m->w[TFR_BU]; L.a[1].bias_m = m->m[TFR_BU]; L.a[1].bias_v = m->v[TFR_BU];
+            L.a[1].frozen_rows = (m->frozen >> TFR_P) & 1; L.a[1].frozen_bias = (m->frozen >> TFR_BU) & 1;
+            L.f = f;
+            {
+                Prof p(m, TFR_K_APPLY);
+                launch_dense_tiles(L, false, true, m->G, m->VEC, s);
+            }
+            HIPCHK(hipGetLastError());
+            fin_done = true;
+        } else {
         RedArgs r;
         memset(&r, 0, sizeof(r));
         r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
@@ -756,8 +812,9 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             }
         }
         HIPCHK(hipGetLastError());
+        }
     }
-    if (tf1) {
+    if (tf1 && !tiles) {
         // dense sweeps: every row of every unfrozen table moves; one launch
         Prof p(m, TFR_K_APPLY);
         DenseArgs d;

@@ -42,6 +42,7 @@ struct RedArgs {
     const int32_t* err;
     int64_t B;
     int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;
+    int32_t tile;                                  // >0: the sorted order restarts every `tile` entries
     float lam, alpha, b1, b2, eps, lr;
 };
 struct RedPair { RedArgs a[2]; };
@@ -82,6 +83,20 @@ struct FinArgs {
     float alpha, b1, b2, eps, lr;
 };
 
+// small-table sweep over per-tile partial gradients (k_dense_tiles)
+struct TileDenseArgs {
+    const int32_t* tab;                            // [ntiles * nbins]: (count << 16) | offset, from the tile-local sort
+    const float* grad_rows; const float* grad_bias;   // piece sums by tile-sorted position
+    float* w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
+    float* out_rows; float* out_bias;              // WRITE mode: dense gradient buffer (data parallel)
+    const int32_t* err;
+    int64_t rows;
+    int32_t D, nbins, ntiles, frozen_rows, frozen_bias, opt, skip_untouched;
+    float alpha, b1, b2, eps, lr;
+};
+struct TileDenseLaunch { TileDenseArgs a[2]; FinArgs f; };
+void launch_dense_tiles(const TileDenseLaunch& L, bool write, bool with_fin, int G, int VEC, hipStream_t s);
+
 // one-pass stable counting sort of both id columns (small tables: all bins fit in LDS)
 struct CSortArgs {
     const int32_t* keys[2];      // [B] each
@@ -114,6 +129,7 @@ struct FrontArgs {
     FwdArgs f; CSortArgs c;
     int32_t* key_out[2];         // fused-gather mode: where the rank blocks publish the gathered ids
     int32_t nfwd;                // number of forward blocks (1024 threads each)
+    int32_t tile_local;          // 1: sort each tile locally (hist / offs become per-tile lookup tables)
 };
 
 // row geometry for a dim: returns false if unsupported

@@ -270,18 +270,18 @@ __global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
     __syncthreads();
     const int64_t k = (int64_t)tile * CSORT_TILE + tid;
     const bool valid = k < a.B;
-    int32_t key = 0;
+    int32_t key = 0, fullkey = 0;
     if (valid) {
         if (fa.f.ids) {
             int64_t id = fa.f.ids[k];
             if ((uint64_t)id >= (uint64_t)fa.f.N) id = 0;          // flagged by the forward blocks
             const int4 rec = fa.f.store[id];
-            key = col == 0 ? rec.x : rec.y;
-            fa.key_out[col][k] = key;
+            fullkey = col == 0 ? rec.x : rec.y;
+            fa.key_out[col][k] = fullkey;
         } else {
-            key = a.keys[col][k];
+            fullkey = a.keys[col][k];
         }
-        key &= nb - 1;
+        key = fullkey & (nb - 1);
     }
     unsigned long long mask = __ballot(valid);
     for (int bit = 1; bit < nb; bit <<= 1) {
@@ -300,8 +300,39 @@ __global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
         }
         __syncthreads();
     }
-    if (valid) a.lrank[col][k] = base + rank_in_wave;
-    for (int b = tid; b < nb; b += CSORT_TILE) a.hist[col][(size_t)tile * nb + b] = cnt[b];
+    if (!fa.tile_local) {
+        if (valid) a.lrank[col][k] = base + rank_in_wave;
+        for (int b = tid; b < nb; b += CSORT_TILE) a.hist[col][(size_t)tile * nb + b] = cnt[b];
+        return;
+    }
+    // tile-local sort: the tile's entries are put in key order right here (no global scan / scatter
+    // launches).  hist[tile][bin] = (entries of the tile with that key) << 16 | (where they start inside
+    // the tile's sorted list); the sweep finds a row's per-tile runs through this table.
+    __shared__ int32_t wtot[CSORT_TILE / 64];
+    const int per = (nb + CSORT_TILE - 1) / CSORT_TILE;          // bins per thread, contiguous
+    int32_t sum = 0;
+    for (int q = 0; q < per; ++q) { const int b = tid * per + q; if (b < nb) sum += cnt[b]; }
+    int32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+    for (int q = 0; q < per; ++q) {                               // in place: (count << 16) | start offset
+        const int b = tid * per + q;
+        if (b < nb) { const int32_t c2 = cnt[b]; cnt[b] = (c2 << 16) | run; run += c2; }
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += CSORT_TILE) a.hist[col][(size_t)tile * nb + b] = cnt[b];     // packed lookup table
+    if (valid) {
+        const int64_t dst = (int64_t)tile * CSORT_TILE + (cnt[key] & 0xffff) + base + rank_in_wave;
+        a.ks[col][dst] = fullkey;
+        a.ps[col][dst] = (int32_t)k;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -399,7 +430,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         pos = a.ps[j];
     }
     if (err || blk0 >= a.B) return;          // an out-of-range id voids the whole step (block-uniform)
-    const bool head = valid && (prev != row);
+    // tile mode: the sorted order is per 1024-entry tile, so a run also starts at every tile start
+    const bool head = valid && (prev != row || (a.tile && (j % a.tile) == 0));
     const bool pstart = valid && (head || grp == 0);
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
     const size_t roff = (size_t)(valid ? row : 0) * D;
@@ -484,7 +516,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         if (!go) break;
     }
     bool cont = false;                                   // does the run continue in the next block?
-    if (e == EPB && blk0 + EPB < a.B) cont = (a.ks[blk0 + EPB] == row);
+    if (e == EPB && blk0 + EPB < a.B && !(a.tile && ((blk0 + EPB) % a.tile) == 0)) cont = (a.ks[blk0 + EPB] == row);
     const bool whole = head && !cont;
     if (RMODE == RMODE_SCRATCH && whole && a.dense_rows) {
         // dense-gradient form (TF1 Adam sweep / data parallel): a run that lies in one block goes
@@ -718,6 +750,125 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
 }
 
 // ------------------------------------------------------------------------------------
+// K5c  small-table sweep over per-tile partials.  With the tile-local sort (k_front) a row's
+//      gradient is spread over the <= 16 tiles of the batch: tab[t][row] packs how many entries tile t
+//      has for the row (<< 16) and where its run starts in the tile's sorted list; the run's piece
+//      sums (k_seg_reduce) sit at that position and at the following multiples of EPB.  One lane
+//      group per row adds them in tile order = batch order (all addresses come from the two lookup
+//      tables, so the loads are independent) and then either applies the optimiser (TF1 Adam: every
+//      row; lazy Adam / SGD: touched rows) or - data parallel - writes the row into the dense
+//      gradient buffer.  blockIdx.y == 2 runs the step's finalize (K4).
+template <int G, int VEC, bool WRITE>
+__global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
+    if (blockIdx.y == 2) {
+        if (blockIdx.x == 0) finalize_body(L.f);
+        return;
+    }
+    const TileDenseArgs& a = L.a[blockIdx.y];
+    if (*a.err) return;
+    constexpr int GPB = 256 / G;
+    constexpr int EPB = 1024 / G;
+    const int gl = threadIdx.x % G;
+    const int d0 = gl * VEC;
+    const int D = a.D;
+    const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
+    for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / G; row < a.rows;
+         row += (int64_t)gridDim.x * GPB) {
+        const size_t roff = (size_t)row * D;
+        Frag<VEC> w, mrow, vrow;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
+        float bw = 0.f, mb = 0.f, vb = 0.f;
+        if constexpr (!WRITE) {                          // independent of the lookups: issue first
+            if (!a.frozen_rows) {
+                w = load_frag<VEC>(a.w + roff, d0, D);
+                if (a.opt == 0) {
+                    mrow = load_frag<VEC>(a.m + roff, d0, D);
+                    vrow = load_frag<VEC>(a.v + roff, d0, D);
+                }
+            }
+            if (gl == 0 && !a.frozen_bias) {
+                bw = a.bias_w[row];
+                if (a.opt == 0) { mb = a.bias_m[row]; vb = a.bias_v[row]; }
+            }
+        }
+        Frag<VEC> tot;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) tot.v[q] = 0.f;
+        float gb = 0.f;
+        bool touched = false;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half * 8 < a.ntiles) {                   // uniform
+                int32_t cn[8], of[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int tt = half * 8 + t;
+                    const int32_t e = (tt < a.ntiles) ? a.tab[(size_t)tt * a.nbins + row] : 0;
+                    cn[t] = e >> 16;                      // entries of tile tt for this row (<= 1024)
+                    of[t] = e & 0xffff;                   // where its run starts in the tile's sorted list
+                }
+                Frag<VEC> x[8];
+                float xb[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {            // unconditional loads (safe address when absent)
+                    const int64_t j = cn[t] ? (int64_t)(half * 8 + t) * 1024 + of[t] : 0;
+                    x[t] = load_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D);
+                    xb[t] = a.grad_bias[j];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (cn[t]) {
+                        touched = true;
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) tot.v[q] += x[t].v[q];
+                        gb += xb[t];
+                        const int64_t j = (int64_t)(half * 8 + t) * 1024 + of[t];
+                        const int64_t end = j + cn[t];
+                        for (int64_t p = (j / EPB + 1) * EPB; p < end; p += EPB) {     // further pieces (hot rows)
+                            const Frag<VEC> y = load_frag<VEC>(a.grad_rows + (size_t)p * D, d0, D);
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) tot.v[q] += y.v[q];
+                            gb += a.grad_bias[p];
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (WRITE) {
+            if (touched) {
+                store_frag<VEC>(a.out_rows + roff, d0, D, tot);
+                if (gl == 0) a.out_bias[row] = gb;
+            }
+        } else {
+            if (!touched && a.skip_untouched) continue;
+            if (!a.frozen_rows) {
+                if (a.opt == 0) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], tot.v[q], c);
+                    store_frag<VEC>(a.m + roff, d0, D, mrow);
+                    store_frag<VEC>(a.v + roff, d0, D, vrow);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * tot.v[q];
+                }
+                store_frag<VEC>(a.w + roff, d0, D, w);
+            }
+            if (gl == 0 && !a.frozen_bias) {
+                if (a.opt == 0) {
+                    adam_sparse(bw, mb, vb, gb, c);
+                    a.bias_m[row] = mb;
+                    a.bias_v[row] = vb;
+                } else {
+                    bw = bw - a.lr * gb;
+                }
+                a.bias_w[row] = bw;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // K4  finalize (body in finalize.inc.h; the small-table path runs it inside the csort scan launch)
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a) { finalize_body(a); }
 
@@ -848,6 +999,24 @@ void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipSt
     TFR_APP_CASE(4, 4) TFR_APP_CASE(8, 4) TFR_APP_CASE(16, 4) TFR_APP_CASE(32, 4) TFR_APP_CASE(64, 4)
     TFR_APP_CASE(4, 1) TFR_APP_CASE(8, 1) TFR_APP_CASE(16, 1) TFR_APP_CASE(32, 1) TFR_APP_CASE(64, 1)
 #undef TFR_APP_CASE
+}
+
+void launch_dense_tiles(const TileDenseLaunch& L, bool write, bool with_fin, int G, int VEC, hipStream_t s) {
+    const int gpb = 256 / G;
+    int64_t rows = L.a[0].rows > L.a[1].rows ? L.a[0].rows : L.a[1].rows;
+    int64_t nb = (rows + gpb - 1) / gpb;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    const dim3 grid((int)nb, with_fin ? 3 : 2);
+#define TFR_DT_CASE(g, v)                                                                         \
+    if (G == g && VEC == v) {                                                                     \
+        if (write) hipLaunchKernelGGL((k_dense_tiles<g, v, true>), grid, dim3(256), 0, s, L);     \
+        else hipLaunchKernelGGL((k_dense_tiles<g, v, false>), grid, dim3(256), 0, s, L);          \
+        return;                                                                                   \
+    }
+    TFR_DT_CASE(4, 4) TFR_DT_CASE(8, 4) TFR_DT_CASE(16, 4) TFR_DT_CASE(32, 4) TFR_DT_CASE(64, 4)
+    TFR_DT_CASE(4, 1) TFR_DT_CASE(8, 1) TFR_DT_CASE(16, 1) TFR_DT_CASE(32, 1) TFR_DT_CASE(64, 1)
+#undef TFR_DT_CASE
 }
 
 void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s) {
