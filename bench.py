@@ -79,7 +79,7 @@ def algo_bytes(kernel, B, D, U, I, adam_mode):
     if kernel == "forward":                 # 2 rows + 2 biases + 2 ids + rating + g out (+24 fused loss)
         return B * (8 * D + 24)
     if kernel == "reduce_item":             # partner row + own row + scratch row out + g, id, pos, key
-        return B * (12 * D + 24) * (2 if adam_mode == "tf1" else 1)     # tf1: both sides in one launch
+        return B * (12 * D + 24) * (2 if B <= 16384 and U + I <= 32768 else 1)   # small tables: both sides in one launch
     if kernel == "reduce_user":
         if adam_mode == "lazy":             # partner row + own w,m,v read + w,m,v write + bias slots
             return B * (28 * D + 16 + 24)
@@ -398,9 +398,10 @@ def main():
     launches_per_step = kern[dom]["launches"] / kp
     avg_s = kern[dom]["total_ms"] / kern[dom]["launches"] * 1e-3
     gbs = per_launch / launches_per_step / avg_s / 1e9 if avg_s > 0 else 0.0
-    symbols = {"forward": "k_front (forward + fused gather + csort rank) / k_forward", "sort": "k_csort_scan(+finalize) + k_csort_scatter / k_rsort_*",
-               "reduce_item": "k_seg_reduce<scratch> (tf1: item+user sides in one launch)", "reduce_user": "k_seg_reduce<adam|sgd> (fused apply)",
-               "apply": "k_adam_dense (tf1 sweep, both tables) / k_apply_rows", "finalize": "k_finalize", "gather": "k_gather_triples"}
+    symbols = {"forward": "k_front (forward + fused gather + tile-local counting sort) / k_forward", "sort": "k_csort_* / k_rsort_*",
+               "reduce_item": "k_seg_reduce<scratch> (small tables: item+user sides in one launch)", "reduce_user": "k_seg_reduce<adam|sgd> (fused apply)",
+               "apply": "k_dense_tiles (combine per-tile partials + optimiser + finalize) / k_adam_dense / k_apply_rows", "finalize": "k_finalize",
+               "gather": "k_gather_triples"}
     roofline = dict(kernel=dom, kernel_symbol=symbols.get(dom, dom), bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
                     traffic=None, algorithmic_bytes_per_step=per_launch, avg_launch_us=avg_s * 1e6,
                     note="tables (2.6 MB + Adam state) are L2/Infinity-Cache resident at this size; "
