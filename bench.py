@@ -393,6 +393,15 @@ def main():
     prof = m.profile_read()
     m.profile(False)
     kern = {k: dict(total_ms=v[0], launches=v[1], avg_us=(v[0] / v[1] * 1e3 if v[1] else 0.0)) for k, v in prof.items()}
+    # The event packets add small gaps between these ~10 us kernels, so the raw event intervals sum to
+    # more than the un-instrumented step.  The kernels of a step run back to back, so each kernel's
+    # share of the event total is applied to the exact step time measured above.
+    ev_step_us = sum(v["total_ms"] for v in kern.values()) / kp * 1e3
+    scale = min(1.0, (ms_per_step * 1e3) / ev_step_us) if ev_step_us > 0 else 1.0
+    for v in kern.values():
+        v["raw_event_avg_us"] = v["avg_us"]
+        v["avg_us"] = v["avg_us"] * scale
+        v["total_ms"] = v["total_ms"] * scale
     dom = max((k for k in kern if kern[k]["launches"]), key=lambda k: kern[k]["total_ms"])
     per_launch = algo_bytes(dom, B, D, U, I, wl["adam_mode"])
     launches_per_step = kern[dom]["launches"] / kp
@@ -406,7 +415,9 @@ def main():
                     traffic=None, algorithmic_bytes_per_step=per_launch, avg_launch_us=avg_s * 1e6,
                     note="tables (2.6 MB + Adam state) are L2/Infinity-Cache resident at this size; "
                          "the HBM-bound measurement is north_star_forward",
-                    kernels={k: round(v["avg_us"], 3) for k, v in kern.items() if v["launches"]})
+                    kernels={k: round(v["avg_us"], 3) for k, v in kern.items() if v["launches"]},
+                    raw_event_us={k: round(v["raw_event_avg_us"], 3) for k, v in kern.items() if v["launches"]},
+                    timing="HIP events on the model's stream over %d steps, normalised to the un-instrumented step time" % kp)
     m.close()
 
     metric = "training ratings/sec, MovieLens-1M SVD dim=64 @1 GPU (+ val RMSE)" if args.workload == "c2" \
