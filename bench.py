@@ -393,11 +393,12 @@ def main():
     prof = m.profile_read()
     m.profile(False)
     kern = {k: dict(total_ms=v[0], launches=v[1], avg_us=(v[0] / v[1] * 1e3 if v[1] else 0.0)) for k, v in prof.items()}
-    # The event packets add small gaps between these ~10 us kernels, so the raw event intervals sum to
-    # more than the un-instrumented step.  The kernels of a step run back to back, so each kernel's
-    # share of the event total is applied to the exact step time measured above.
+    # Event intervals around ~10 us kernels carry a +-2 us error (packet gaps one way, the calibrated
+    # empty-pair overhead the other).  The kernels of a step run back to back (rocprof: their durations
+    # sum to the step time), so each kernel's SHARE of the event total is applied to the exact,
+    # un-instrumented step time measured above.
     ev_step_us = sum(v["total_ms"] for v in kern.values()) / kp * 1e3
-    scale = min(1.0, (ms_per_step * 1e3) / ev_step_us) if ev_step_us > 0 else 1.0
+    scale = (ms_per_step * 1e3) / ev_step_us if ev_step_us > 0 else 1.0
     for v in kern.values():
         v["raw_event_avg_us"] = v["avg_us"]
         v["avg_us"] = v["avg_us"] * scale
