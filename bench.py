@@ -315,8 +315,12 @@ def main():
     if os.environ.get("TFR_SHARE_GPU"):          # rehearsal on a 1-GPU box: every rank on device 0
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dp = world == 1 and bool(os.environ.get("TFR_FORCE_DP"))     # 1-rank rehearsal of the N>1 step
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("TFR_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -342,7 +346,7 @@ def main():
     K, W = args.steps, args.warmup
 
     gen = synth_movielens if args.workload in ("c1", "c2") else synth_uniform
-    if world > 1:
+    if world > 1 or force_dp:
         # tables every GPU can hold -> data parallel (one gradient all-reduce per step); tables at
         # the scale sharding is meant for -> row-sharded with all-to-all row exchange
         small = (U + I) * (D + 1) * 4 <= 256 << 20 and wl["adam_mode"] == "tf1"

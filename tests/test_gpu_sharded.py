@@ -111,6 +111,12 @@ def test_two_rank_data_parallel_equals_one_global_step(kw):
     mp.spawn(_dp_worker, args=(2, _free_port(), kw, 300, 200, 64, 1500, 4), nprocs=2, join=True)
 
 
+def test_two_rank_data_parallel_large_table_route():
+    # > 16384 rows: the global sort + dense_rows route instead of the tile-local one
+    mp.spawn(_dp_worker, args=(2, _free_port(), dict(optimizer="adam", adam_mode="tf1"), 20000, 17000, 32, 3000, 3),
+             nprocs=2, join=True)
+
+
 def test_data_parallel_rejects_lazy_adam():
     import tfrecomm_amd as T
     with T.SvdModel(10, 10, 8, optimizer="adam", adam_mode="lazy") as m:

@@ -1437,7 +1437,47 @@ int tfr_dp_local_grads(tfr_model* m, const int32_t* du, const int32_t* di, const
     memset(&f, 0, sizeof(f));
     f.partials = m->partials; f.scalars = m->scalars; f.out = tail; f.err = m->d_err;
     f.mu = m->w[TFR_MU];
-    if (B > 0) {
+    if (B > 0 && tiles_eligible(m, B)) {
+        // small tables: tile-local order, per-tile piece sums, then one sweep that writes every touched
+        // row's gradient into the flat buffer and reduces the local scalars (K4 without the mu update)
+        if ((rc = front_and_sort(m, du, di, dr, B, nullptr, d_store_ids, f, nblk, fin_done, true))) return rc;
+        RedArgs r;
+        memset(&r, 0, sizeof(r));
+        r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D; r.tile = CSORT_TILE;
+        r.item_abs = o.item_abs; r.reg_bias = o.reg_bias; r.lam = o.reg;
+        RedPair pr;
+        pr.a[0] = r;
+        pr.a[0].side = 1; pr.a[0].ks = m->ks_i; pr.a[0].ps = m->ps_i; pr.a[0].other = du;
+        pr.a[0].own = m->w[TFR_Q]; pr.a[0].partner = m->w[TFR_P]; pr.a[0].own_bias = m->w[TFR_BI];
+        pr.a[0].grad_rows = m->gq; pr.a[0].grad_bias = m->gbq;
+        pr.a[1] = r;
+        pr.a[1].side = 0; pr.a[1].ks = m->ks_u; pr.a[1].ps = m->ps_u; pr.a[1].other = di;
+        pr.a[1].own = m->w[TFR_P]; pr.a[1].partner = m->w[TFR_Q]; pr.a[1].own_bias = m->w[TFR_BU];
+        pr.a[1].grad_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D; pr.a[1].grad_bias = m->gbp;
+        {
+            Prof p(m, TFR_K_REDUCE_ITEM);
+            launch_seg_reduce(pr, 2, RMODE_SCRATCH, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        TileDenseLaunch L;
+        memset(&L, 0, sizeof(L));
+        TileDenseArgs d;
+        memset(&d, 0, sizeof(d));
+        d.err = m->d_err; d.D = m->D; d.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+        L.a[0] = d;
+        L.a[0].tab = m->hist_i; L.a[0].nbins = 1 << m->bits_i; L.a[0].rows = m->I;
+        L.a[0].grad_rows = m->gq; L.a[0].grad_bias = m->gbq; L.a[0].out_rows = gQ; L.a[0].out_bias = gbi;
+        L.a[1] = d;
+        L.a[1].tab = m->hist_u; L.a[1].nbins = 1 << m->bits_u; L.a[1].rows = m->U;
+        L.a[1].grad_rows = pr.a[1].grad_rows; L.a[1].grad_bias = m->gbp; L.a[1].out_rows = gP; L.a[1].out_bias = gbu;
+        L.f = f;
+        {
+            Prof p(m, TFR_K_APPLY);
+            launch_dense_tiles(L, true, true, m->G, m->VEC, s);
+        }
+        HIPCHK(hipGetLastError());
+        fin_done = true;
+    } else if (B > 0) {
         if ((rc = front_and_sort(m, du, di, dr, B, nullptr, d_store_ids, f, nblk, fin_done))) return rc;
         RedArgs r;
         memset(&r, 0, sizeof(r));
@@ -1511,23 +1551,18 @@ int tfr_dp_apply(tfr_model* m, float* d_flat) {
     dp.a[1].w = m->w[TFR_Q]; dp.a[1].m = m->m[TFR_Q]; dp.a[1].v = m->v[TFR_Q];
     dp.a[1].bias_w = m->w[TFR_BI]; dp.a[1].bias_m = m->m[TFR_BI]; dp.a[1].bias_v = m->v[TFR_BI];
     dp.a[1].frozen_rows = (m->frozen >> TFR_Q) & 1; dp.a[1].frozen_bias = (m->frozen >> TFR_BI) & 1;
-    {
-        Prof p(m, TFR_K_APPLY);
-        launch_adam_dense(dp, 2, m->G, m->VEC, m->stream);
-    }
-    HIPCHK(hipGetLastError());
-    FinArgs f;
+    FinArgs f;                         // bias_global from the all-reduced {loss, reg, sum g}; rides in the sweep
     memset(&f, 0, sizeof(f));
     f.partials = tail; f.nblk = 1; f.scalars = m->scalars; f.out = nullptr;
     f.mu = m->w[TFR_MU]; f.mu_m = m->m[TFR_MU]; f.mu_v = m->v[TFR_MU]; f.err = m->d_err;
     f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
     f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
+    f.clear_partials = 1;                                        // scalars consumed: clean for the next step
     {
-        Prof p(m, TFR_K_FINALIZE);
-        launch_finalize(f, m->stream);
+        Prof p(m, TFR_K_APPLY);
+        launch_adam_dense(dp, 2, m->G, m->VEC, m->stream, &f);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(tail, 0, 16, m->stream));              // scalars consumed
     if (adam) {
         m->b1p *= o.beta1;
         m->b2p *= o.beta2;

@@ -73,15 +73,16 @@ struct DenseArgs {
     int32_t D, frozen_rows, frozen_bias, opt;    // opt: 0 Adam, 1 SGD
     float alpha, b1, b2, eps, lr;
 };
-struct DensePair { DenseArgs a[2]; };
-
 struct FinArgs {
     const float* partials; int32_t nblk;
     float* scalars; float* out;
     float* mu; float* mu_m; float* mu_v; const int32_t* err;
-    int32_t update_mu, opt;
+    int32_t update_mu, opt, clear_partials;        // clear_partials: zero partials[0..3] after use
     float alpha, b1, b2, eps, lr;
 };
+
+struct DensePair { DenseArgs a[2]; FinArgs f; };
+
 
 // small-table sweep over per-tile partial gradients (k_dense_tiles)
 struct TileDenseArgs {
@@ -151,7 +152,7 @@ void launch_front(const FrontArgs& fa, int G, int VEC, hipStream_t s);
 void launch_csort_tail(const CSortArgs& a, const FinArgs* fin, hipStream_t s);   // scan (+K4) and scatter only
 void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s);
 void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipStream_t s);
-void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s);
+void launch_adam_dense(DensePair& p, int n, int G, int VEC, hipStream_t s, const FinArgs* fin = nullptr);
 void launch_gather(const GatherArgs& a, hipStream_t s);
 void launch_gather_rows(const GatherRowsArgs& a, int G, int VEC, hipStream_t s);
 void launch_pack_triples(const int32_t* u, const int32_t* it, const float* r, void* store, int64_t n, hipStream_t s);

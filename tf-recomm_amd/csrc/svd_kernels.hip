@@ -677,6 +677,10 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
 template <int G, int VEC>
 __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
     constexpr int PIECE = 1024 / G;
+    if (blockIdx.y == 2) {                               // optional: the step's K4 rides in this launch
+        if (blockIdx.x == 0) finalize_body(pr.f);
+        return;
+    }
     const DenseArgs& a = pr.a[blockIdx.y];
     if (*a.err) return;
     constexpr int GPB = 256 / G;
@@ -1019,7 +1023,8 @@ void launch_dense_tiles(const TileDenseLaunch& L, bool write, bool with_fin, int
 #undef TFR_DT_CASE
 }
 
-void launch_adam_dense(const DensePair& p, int n, int G, int VEC, hipStream_t s) {
+void launch_adam_dense(DensePair& p, int n, int G, int VEC, hipStream_t s, const FinArgs* fin) {
+    if (fin) { p.f = *fin; n = 3; }
     const int gpb = 256 / G;
     int64_t rows = p.a[0].rows;
     if (n > 1 && p.a[1].rows > rows) rows = p.a[1].rows;

@@ -29,19 +29,32 @@ class HipReplica(object):
         self.model.set_stream(self.stream.cuda_stream)
         self.flat = torch.zeros(self.model.dp_flat_size(), dtype=torch.float32, device=self.device)
 
+    # The model's kernels run on self.stream.  When the caller has made that torch's current
+    # stream (bench_entry does: torch.cuda.set_stream) the collective orders itself against it
+    # and no cross-stream events are needed; otherwise fence both ways.
+    def _foreign(self):
+        cur = torch.cuda.current_stream(self.device)
+        return None if cur == self.stream else cur
+
     def local_grads(self, u=None, i=None, r=None, store_ids_ptr=None, batch=None):
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        cur = self._foreign()
+        if cur is not None:
+            self.stream.wait_stream(cur)
         if store_ids_ptr is not None:
             self.model.dp_local_grads(None, None, None, batch, store_ids_ptr, self.flat.data_ptr())
         else:
             self.model.dp_local_grads(u.data_ptr(), i.data_ptr(), r.data_ptr(), u.numel(), None, self.flat.data_ptr())
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        if cur is not None:
+            cur.wait_stream(self.stream)
         return self.flat
 
     def apply(self, flat):
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        cur = self._foreign()
+        if cur is not None:
+            self.stream.wait_stream(cur)
         self.model.dp_apply(flat.data_ptr())
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        if cur is not None:
+            cur.wait_stream(self.stream)
 
     def sync(self):
         self.model.sync()
@@ -61,12 +74,12 @@ class DataParallelSvd(object):
             dist.all_reduce(flat, group=self.group)
         return flat
 
-    def train_step(self, u=None, i=None, r=None, store_ids_ptr=None, batch=None):
-        """This rank's slice of the global batch.  Returns the flat buffer's tail view
-        {loss, reg, sum_g} (global sums) - read it before the next step."""
+    def train_step(self, u=None, i=None, r=None, store_ids_ptr=None, batch=None, want_scalars=True):
+        """This rank's slice of the global batch.  Returns a copy of the flat buffer's tail
+        {loss, reg, sum_g, 0} (global sums), or None with ``want_scalars=False``."""
         flat = self.backend.local_grads(u, i, r, store_ids_ptr, batch)
         self._all_reduce(flat)
-        scal = flat[-4:].clone()
+        scal = flat[-4:].clone() if want_scalars else None
         self.backend.apply(flat)
         return scal
 
@@ -84,9 +97,10 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val):
     base, _ = be.model.staged_ids_devptr()
     dp = DataParallelSvd(be)
     stage = dp.stage
+    torch.cuda.set_stream(be.stream)                   # the collective queues behind the model's kernels
 
     def step(s):
-        dp.train_step(store_ids_ptr=base + s * B * 8, batch=B)
+        dp.train_step(store_ids_ptr=base + s * B * 8, batch=B, want_scalars=False)
     for s in range(W):
         step(s)
     be.sync()
