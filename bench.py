@@ -105,7 +105,7 @@ def profiled_traffic(kernel_substr):
     rd = wr = None
     for line in open(path):
         f = line.strip().split(",")
-        if len(f) >= 4 and kernel_substr in line:
+        if len(f) >= 4 and (kernel_substr + '"') in line:
             if f[-5] == "TCC_EA0_RDREQ_sum":
                 rd = float(f[-3]) * 128.0
             if f[-5] == "WRITE_SIZE":
@@ -191,7 +191,8 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
                 workload="%d users x %d items, dim=%d, batch=%d, %s ids" % (U, I, D, B, "Zipf(%.2f) item" % zipf if zipf > 0 else
                                                                           ("sequential" if sequential else "uniform")),
                 bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                traffic=profiled_traffic("k_forward<32, 4, 0") if (U, I, D, B, zipf) == (10_000_000, 1_000_000, 128, 262144, 0.0) else None,
+                traffic=profiled_traffic("k_forward<32, 4, 0, 4> [%s]" % ("zipf" if zipf > 0 else "uniform"))
+                if (U, I, D, B) == (10_000_000, 1_000_000, 128, 262144) and zipf in (0.0, 1.05) and not sequential else None,
                 traffic_source="profiles/r01_pmc_summary.csv (rocprofv3 --pmc, separate passes)",
                 algorithmic_bytes_per_launch=per_launch, avg_launch_us=ms / n * 1e3,
                 ratings_per_s=B * n / (ms * 1e-3), wall_ratings_per_s=B * steps / wall,
@@ -417,7 +418,10 @@ def main():
                "apply": "k_dense_tiles (combine per-tile partials + optimiser + finalize) / k_adam_dense / k_apply_rows", "finalize": "k_finalize",
                "gather": "k_gather_triples"}
     roofline = dict(kernel=dom, kernel_symbol=symbols.get(dom, dom), bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                    traffic=None, algorithmic_bytes_per_step=per_launch, avg_launch_us=avg_s * 1e6,
+                    traffic=profiled_traffic({"forward": "k_front<16, 4>", "reduce_item": "k_seg_reduce<16, 4, 0>",
+                                              "apply": "k_dense_tiles<16, 4, false>"}.get(dom, "-")) if args.workload == "c2" else None,
+                    traffic_source="profiles/r01_pmc_summary.csv: L2<->fabric requests of this kernel (served by the Infinity Cache at this size)",
+                    algorithmic_bytes_per_step=per_launch, avg_launch_us=avg_s * 1e6,
                     note="tables (2.6 MB + Adam state) are L2/Infinity-Cache resident at this size; "
                          "the HBM-bound measurement is north_star_forward",
                     kernels={k: round(v["avg_us"], 3) for k, v in kern.items() if v["launches"]},
