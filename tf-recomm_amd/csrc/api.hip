@@ -179,8 +179,9 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     if ((rc = dmalloc(&m->ks2_i, cap))) return rc;
     if ((rc = dmalloc(&m->ps2_i, cap))) return rc;
     const bool tf1_ws = m->o.optimizer == TFR_OPT_ADAM && m->o.adam_mode == TFR_ADAM_TF1;
-    // non-tf1: second half of gq parks the pieces of split user runs
-    if ((rc = dmalloc(&m->gq, (size_t)cap * m->D * (tf1_ws ? 1 : 2)))) return rc;
+    // non-tf1: second third of gq parks the pieces of split user runs, the last third the
+    // per-entry copies of pre-update item rows the fused user side reads
+    if ((rc = dmalloc(&m->gq, (size_t)cap * m->D * (tf1_ws ? 1 : 3)))) return rc;
     if ((rc = dmalloc(&m->gbq, cap))) return rc;
     if ((rc = dmalloc(&m->gbp, cap))) return rc;
     if (tf1_ws)
@@ -774,14 +775,22 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             Prof p(m, TFR_K_REDUCE_ITEM);
             launch_seg_reduce(pr, 2, RMODE_SCRATCH, m->G, m->VEC, s);
         } else {
-            // the user side updates P in place, so the item side (which reads P) goes first.
-            // Pieces of split user runs are parked in the second half of gq (2*cap rows).
+            // both sides fused (reduce + lazy Adam / SGD in place).  The item side goes first and
+            // leaves a per-entry copy of the pre-update Q rows (last third of gq) for the user
+            // side, which then updates P; pieces of runs cut by a block boundary are parked in
+            // the first (items) and second (users) third of gq and finished by k_apply_rows.
+            float* qcopy = m->gq + 2 * (size_t)m->cap * m->D;
+            ri.own_w = m->w[TFR_Q]; ri.m = m->m[TFR_Q]; ri.v = m->v[TFR_Q];
+            ri.bias_w = m->w[TFR_BI]; ri.bias_m = m->m[TFR_BI]; ri.bias_v = m->v[TFR_BI];
+            ri.frozen_rows = (m->frozen >> TFR_Q) & 1; ri.frozen_bias = (m->frozen >> TFR_BI) & 1;
+            ri.own_copy_out = qcopy;
+            ru.partner_by_pos = qcopy;
             ru.grad_rows = m->gq + (size_t)m->cap * m->D;
             RedPair pr;
             pr.a[0] = ri;
             {
                 Prof p(m, TFR_K_REDUCE_ITEM);
-                launch_seg_reduce(pr, 1, RMODE_SCRATCH, m->G, m->VEC, s);
+                launch_seg_reduce(pr, 1, adam ? RMODE_ADAM : RMODE_SGD, m->G, m->VEC, s);
             }
             HIPCHK(hipGetLastError());
             pr.a[0] = ru;
@@ -792,16 +801,15 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             HIPCHK(hipGetLastError());
             ApplyArgs ap;
             memset(&ap, 0, sizeof(ap));
-            ap.err = m->d_err; ap.B = B; ap.D = m->D;
+            ap.err = m->d_err; ap.B = B; ap.D = m->D; ap.only_split = 1;
             ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
             ApplyPair app;
-            app.a[0] = ap;                     // item rows: every run
+            app.a[0] = ap;
             app.a[0].ks = m->ks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
             app.a[0].w = m->w[TFR_Q]; app.a[0].m = m->m[TFR_Q]; app.a[0].v = m->v[TFR_Q];
             app.a[0].bias_w = m->w[TFR_BI]; app.a[0].bias_m = m->m[TFR_BI]; app.a[0].bias_v = m->v[TFR_BI];
-            app.a[0].frozen_rows = (m->frozen >> TFR_Q) & 1; app.a[0].frozen_bias = (m->frozen >> TFR_BI) & 1;
-            app.a[1] = ap;                     // user rows: only the runs cut into several pieces
-            app.a[1].only_split = 1;
+            app.a[0].frozen_rows = ri.frozen_rows; app.a[0].frozen_bias = ri.frozen_bias;
+            app.a[1] = ap;
             app.a[1].ks = m->ks_u; app.a[1].grad_rows = ru.grad_rows; app.a[1].grad_bias = m->gbp;
             app.a[1].w = m->w[TFR_P]; app.a[1].m = m->m[TFR_P]; app.a[1].v = m->v[TFR_P];
             app.a[1].bias_w = m->w[TFR_BU]; app.a[1].bias_m = m->m[TFR_BU]; app.a[1].bias_v = m->v[TFR_BU];

@@ -39,6 +39,8 @@ struct RedArgs {
     float* dense_rows; float* dense_bias;          // optional dense [rows,D] / [rows] gradient buffers
     const float* rows_in; const float* bias_in;    // sharded owner side: pre-reduced gradient rows
     const float* lam_arr;                          // optional per-entry coefficient of the own row (FM)
+    float* own_copy_out;                           // optional [B,D]: the entry's pre-update own row, by batch position
+    const float* partner_by_pos;                   // optional [B,D]: read the partner row from such a copy instead
     const int32_t* err;
     int64_t B;
     int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;

@@ -408,6 +408,9 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 //     RMODE_SCRATCH : every piece sum -> scratch[piece start] (+ map[row] = head+1 for tf1)
 //     RMODE_ADAM/SGD: a run that lies inside one block is applied in place at once (fused lazy
 //                     Adam / SGD); split runs go to scratch and k_apply_rows finishes them.
+//     Both sides run fused: the item side goes first and copies each entry's pre-update Q row
+//     to own_copy_out[pos]; the user side then takes its partner rows from that copy
+//     (partner_by_pos), so neither side sees a row the other has already moved.
 template <int G, int VEC, int RMODE>
 __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     constexpr int EPB = 1024 / G;
@@ -459,7 +462,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         const float gk = a.g[pos];
         const int32_t pid = a.other[pos];
         const float lam_e = a.lam_arr ? a.lam_arr[pos] : a.lam;      // FM: lam - g x^2 per non-zero
-        const Frag<VEC> x = load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
+        const Frag<VEC> x = a.partner_by_pos ? load_frag<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D)
+                                             : load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
         o = load_frag<VEC>(a.own + roff, d0, D);
         ob = a.own_bias[row];
         if constexpr (RMODE == RMODE_ADAM) {
@@ -470,6 +474,9 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
                 vb = a.bias_v[row];
             }
         }
+        // this side updates its table in place before the other side runs: leave the other side the
+        // pre-update row it needs, per entry
+        if (a.own_copy_out) store_frag<VEC>(a.own_copy_out + (size_t)pos * D, d0, D, o);
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             float xv = x.v[q];
@@ -613,14 +620,30 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
     const int gl = threadIdx.x % G;
     const int d0 = gl * VEC;
     const int D = a.D;
-    const int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
-    if (j >= a.B) return;
-    const int32_t row = a.ks[j];
-    const int32_t prev = (j > 0) ? a.ks[j - 1] : -2;
-    if (err || prev == row) return;                      // voided step / not a run head
+    int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+    int32_t row;
     if (a.only_split) {
-        const int64_t p = (j / PIECE + 1) * PIECE;
-        if (!(p < a.B && a.ks[p] == row)) return;        // single-piece run: already applied
+        // one lane group per piece boundary p: a run is split iff it crosses one.  The first
+        // boundary a run crosses owns it; its head then lies in the PIECE entries before p.
+        const int64_t p = (j + 1) * PIECE;
+        if (err || p >= a.B) return;
+        row = a.ks[p];
+        if (a.ks[p - 1] != row) return;                  // no run crosses this boundary
+        const int64_t lo = p - PIECE;
+        if (lo > 0 && a.ks[lo - 1] == row) return;       // crossed an earlier boundary: handled there
+        const int sh = ((threadIdx.x % 64) / G) * G;     // this group's lanes within the wave
+        j = p - 1;
+        for (int k = 0; k < PIECE; k += G) {             // sorted keys: the matches are a suffix of [lo, p)
+            const bool hit = (k + gl < PIECE) && a.ks[lo + k + gl] == row;
+            unsigned long long bits = __ballot(hit) >> sh;
+            if constexpr (G < 64) bits &= (1ull << G) - 1ull;
+            if (bits) { j = lo + k + (__ffsll((long long)bits) - 1); break; }
+        }
+    } else {
+        if (j >= a.B) return;
+        row = a.ks[j];
+        const int32_t prev = (j > 0) ? a.ks[j - 1] : -2;
+        if (err || prev == row) return;                  // voided step / not a run head
     }
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
     const size_t roff = (size_t)row * D;
@@ -992,6 +1015,9 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
 void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipStream_t s) {
     int64_t B = p.a[0].B;
     if (n > 1 && p.a[1].B > B) B = p.a[1].B;
+    bool all_split = p.a[0].only_split != 0;
+    if (n > 1 && !p.a[1].only_split) all_split = false;
+    if (all_split) B = (B + 1024 / G - 1) / (1024 / G);      // one lane group per piece boundary
     const dim3 grid(entry_grid(B, G), n);
 #define TFR_APP_CASE(g, v)                                                                  \
     if (G == g && VEC == v) {                                                               \
