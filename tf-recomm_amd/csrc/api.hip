@@ -186,7 +186,11 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     if ((rc = dmalloc(&m->gbp, cap))) return rc;
     if (tf1_ws)
         if ((rc = dmalloc(&m->gp, (size_t)cap * m->D))) return rc;
-    if ((rc = dmalloc(&m->partials, (size_t)8192 * 4))) return rc;
+    {   // per-block {loss, reg, sum g}: the forward launches <= 8192 blocks, the reduce with the
+        // forward fused in one block per 1024/G sorted entries
+        const size_t nb = (size_t)(cap + 1024 / m->G - 1) / (1024 / m->G);
+        if ((rc = dmalloc(&m->partials, (nb > 8192 ? nb : 8192) * 4))) return rc;
+    }
     {
         const size_t ntiles = (size_t)(cap + CSORT_TILE - 1) / CSORT_TILE;
         const bool small = (1 << (m->bits_u > m->bits_i ? m->bits_u : m->bits_i)) <= CSORT_MAX_BINS;
@@ -544,7 +548,8 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
 // hand-written LSD radix sort of one or two key columns: column c = (keys[c], bits[c]) ->
 // sorted keys in ks_out[c], original positions in ps_out[c].  ceil(maxbits/8) passes, 3 launches each.
 static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* keys, const int* bits,
-                              int32_t* const* ks_out, int32_t* const* ps_out, int64_t B) {
+                              int32_t* const* ks_out, int32_t* const* ps_out, int64_t B,
+                              const int64_t* limits = nullptr) {
     int maxbits = bits[0];
     if (ncols > 1 && bits[1] > maxbits) maxbits = bits[1];
     const int passes = (maxbits + 7) / 8;
@@ -570,6 +575,8 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
             r.vals_out[c] = to_final ? ps_out[c] : tmpv[c];
         }
         r.shift = 8 * p;
+        r.err = (p == 0 && limits) ? m->d_err : nullptr;         // ids outside the tables void the step
+        if (limits) for (int c = 0; c < ncols; ++c) r.limit[c] = (int32_t)limits[c];
         launch_rsort_pass(r, ncols, m->stream);
     }
     HIPCHK(hipGetLastError());
@@ -578,7 +585,7 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
 
 // stable sort of batch positions by user id and by item id
 static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int64_t B,
-                        const FinArgs* fin = nullptr, bool* fin_done = nullptr) {
+                        const FinArgs* fin = nullptr, bool* fin_done = nullptr, bool validate = false) {
     Prof p(m, TFR_K_SORT);
     if (m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i)) {
         CSortArgs c;
@@ -599,7 +606,15 @@ static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int6
     const int bits[2] = {m->bits_u, m->bits_i};
     int32_t* ks[2] = {m->ks_u, m->ks_i};
     int32_t* ps[2] = {m->ps_u, m->ps_i};
-    return radix_sort_columns(m, 2, keys, bits, ks, ps, B);
+    const int64_t limits[2] = {m->U, m->I};
+    return radix_sort_columns(m, 2, keys, bits, ks, ps, B, validate ? limits : nullptr);
+}
+
+// big tables with a touched-rows optimiser: the forward is computed inside the item-side reduce,
+// which needs the sorted order first - so the step starts with (gather +) sort
+static bool fwd_in_reduce(const tfr_model* m, int64_t B) {
+    const bool tf1 = m->o.optimizer == TFR_OPT_ADAM && m->o.adam_mode == TFR_ADAM_TF1;
+    return B > 0 && !tf1 && !(m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i));
 }
 
 static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t B);
@@ -611,12 +626,19 @@ static bool tiles_eligible(const tfr_model* m, int64_t B) {
     return B > 0 && m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i) && (B + CSORT_TILE - 1) / CSORT_TILE <= 16;
 }
 
-static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, const float* dr, int64_t B,
+static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, const float*& dr, int64_t B,
                           float* d_logits, const int64_t* d_store_ids, FinArgs& f, int& nblk, bool& fin_done,
-                          bool tiles = false) {
+                          bool tiles = false, bool sort_only = false) {
     const tfr_opts& o = m->o;
     hipStream_t s = m->stream;
     int rc;
+    if (sort_only) {
+        if (d_store_ids) {
+            if ((rc = gather_batch(m, d_store_ids, 0, B))) return rc;
+            du = m->d_u; di = m->d_i; dr = m->d_r;
+        }
+        return sort_columns(m, du, di, B, nullptr, nullptr, true);       // + id range check
+    }
     if (d_store_ids && B >= 32768) {
         // big batches are bandwidth-bound: a separate gather keeps the forward's dependent chain
         // at ids -> rows; small batches are launch-bound and gather inside the forward instead
@@ -694,7 +716,8 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     if (B > 0) {
         int rc;
         tiles = tiles_eligible(m, B);
-        if ((rc = front_and_sort(m, du, di, dr, B, d_logits, d_store_ids, f, nblk, fin_done, tiles))) return rc;
+        const bool fwd_fused = fwd_in_reduce(m, B);
+        if ((rc = front_and_sort(m, du, di, dr, B, d_logits, d_store_ids, f, nblk, fin_done, tiles, fwd_fused))) return rc;
         if (tiles) {
             // small tables: per-tile sorted order -> piece sums per tile -> one sweep that combines a
             // row's per-tile partials, applies the optimiser to both tables and runs K4
@@ -786,11 +809,17 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             ri.own_copy_out = qcopy;
             ru.partner_by_pos = qcopy;
             ru.grad_rows = m->gq + (size_t)m->cap * m->D;
+            if (fwd_fused) {           // K1 inside the item side: logits, g, per-block {loss, reg, sum g}
+                ri.partner_bias = m->w[TFR_BU]; ri.mu = m->w[TFR_MU]; ri.r = dr; ri.loss = o.loss;
+                ri.g_out = m->d_g; ri.logits_out = d_logits; ri.partials = m->partials;
+                const int epb = 1024 / m->G;
+                nblk = (int)((B + epb - 1) / epb);
+            }
             RedPair pr;
             pr.a[0] = ri;
             {
                 Prof p(m, TFR_K_REDUCE_ITEM);
-                launch_seg_reduce(pr, 1, adam ? RMODE_ADAM : RMODE_SGD, m->G, m->VEC, s);
+                launch_seg_reduce(pr, 1, adam ? RMODE_ADAM : RMODE_SGD, m->G, m->VEC, s, fwd_fused);
             }
             HIPCHK(hipGetLastError());
             pr.a[0] = ru;

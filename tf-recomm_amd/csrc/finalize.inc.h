@@ -14,10 +14,18 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float acc[3] = {0.f, 0.f, 0.f};
     if (tid < 256) {
-        for (int b = tid; b < a.nblk; b += 256) {
-            acc[0] += a.partials[(size_t)b * 4 + 0];
-            acc[1] += a.partials[(size_t)b * 4 + 1];
-            acc[2] += a.partials[(size_t)b * 4 + 2];
+        for (int b = tid; b < a.nblk; b += 256 * 8) {     // eight independent loads per round trip, added in order
+            float x[8][3];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int bb = (b + q * 256 < a.nblk) ? b + q * 256 : b;         // in-bounds address; masked below
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x[q][c] = a.partials[(size_t)bb * 4 + c];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (b + q * 256 < a.nblk) { acc[0] += x[q][0]; acc[1] += x[q][1]; acc[2] += x[q][2]; }
+            }
         }
     }
 #pragma unroll

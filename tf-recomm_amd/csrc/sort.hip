@@ -176,7 +176,12 @@ __global__ __launch_bounds__(CSORT_TILE) void k_rsort_rank(RSortArgs a) {
     __syncthreads();
     const int64_t k = (int64_t)tile * CSORT_TILE + tid;
     const bool valid = k < a.B;
-    const int32_t digit = valid ? ((a.keys_in[col][k] >> a.shift) & 255) : 0;
+    const int32_t key = valid ? a.keys_in[col][k] : 0;
+    const int32_t digit = (key >> a.shift) & 255;
+    if (a.err && a.shift == 0) {                         // range check rides in the first pass
+        const bool bad = valid && (uint32_t)key >= (uint32_t)a.limit[col];
+        if (__any(bad) && (tid & 63) == 0) atomicOr(a.err, 1);
+    }
     unsigned long long mask = __ballot(valid);
 #pragma unroll
     for (int bit = 1; bit < 256; bit <<= 1) {

@@ -41,6 +41,10 @@ struct RedArgs {
     const float* lam_arr;                          // optional per-entry coefficient of the own row (FM)
     float* own_copy_out;                           // optional [B,D]: the entry's pre-update own row, by batch position
     const float* partner_by_pos;                   // optional [B,D]: read the partner row from such a copy instead
+    // forward fused into this side (FWD kernels): logits, g and the per-block {loss, reg, sum g}
+    // are produced here from the rows the reduce loads anyway
+    const float* partner_bias; const float* mu; const float* r;
+    float* g_out; float* logits_out; float* partials; int32_t loss;
     const int32_t* err;
     int64_t B;
     int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;
@@ -152,7 +156,7 @@ void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStr
 int front_forward_blocks(int64_t B, int G);
 void launch_front(const FrontArgs& fa, int G, int VEC, hipStream_t s);
 void launch_csort_tail(const CSortArgs& a, const FinArgs* fin, hipStream_t s);   // scan (+K4) and scatter only
-void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s);
+void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s, bool fwd = false);
 void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipStream_t s);
 void launch_adam_dense(DensePair& p, int n, int G, int VEC, hipStream_t s, const FinArgs* fin = nullptr);
 void launch_gather(const GatherArgs& a, hipStream_t s);
@@ -175,6 +179,7 @@ struct RSortArgs {
     int32_t* blocktot[2];                                    // per scan block (chunk entries) totals
     int32_t shift, ntiles, chunk;                            // chunk: multiple of 1024, <= 16384
     int64_t B;
+    int32_t limit[2]; int32_t* err;                          // err != NULL: pass 0 flags keys outside [0, limit)
 };
 void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s);
 

@@ -411,7 +411,7 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 //     Both sides run fused: the item side goes first and copies each entry's pre-update Q row
 //     to own_copy_out[pos]; the user side then takes its partner rows from that copy
 //     (partner_by_pos), so neither side sees a row the other has already moved.
-template <int G, int VEC, int RMODE>
+template <int G, int VEC, int RMODE, bool FWD = false>
 __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     constexpr int EPB = 1024 / G;
     __shared__ float lds_t[EPB * G * VEC];
@@ -441,6 +441,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 
     Frag<VEC> o, t, mrow, vrow;
     float ob = 0.f, tb = 0.f, mb = 0.f, vb = 0.f;
+    float facc[3] = {0.f, 0.f, 0.f};                     // FWD: this lane's {loss, reg, g} share
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { o.v[q] = 0.f; t.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
     if (valid && a.rows_in) {
@@ -459,7 +460,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             }
         }
     } else if (valid) {
-        const float gk = a.g[pos];
+        float gk = 0.f;
+        if constexpr (!FWD) gk = a.g[pos];
         const int32_t pid = a.other[pos];
         const float lam_e = a.lam_arr ? a.lam_arr[pos] : a.lam;      // FM: lam - g x^2 per non-zero
         const Frag<VEC> x = a.partner_by_pos ? load_frag<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D)
@@ -477,6 +479,37 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         // this side updates its table in place before the other side runs: leave the other side the
         // pre-update row it needs, per entry
         if (a.own_copy_out) store_frag<VEC>(a.own_copy_out + (size_t)pos * D, d0, D, o);
+        if constexpr (FWD) {
+            // K1 on the rows already in registers (item side: partner = P[u], own = Q[i]); same
+            // arithmetic and order as forward_body
+            float sdot = 0.f, sq = 0.f;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float qv = o.v[q];
+                sdot = fmaf(x.v[q], a.item_abs ? fabsf(qv) : qv, sdot);
+                sq = fmaf(x.v[q], x.v[q], fmaf(qv, qv, sq));
+            }
+            sdot = group_sum<G>(sdot);
+            const float pb = a.partner_bias[pid];
+            const float logit = ((sdot + *a.mu) + pb) + ob;
+            const float r = a.r[pos];
+            float l;
+            if (a.loss == 0) {
+                gk = logit - r;
+                l = 0.5f * gk * gk;
+            } else {
+                gk = sigmoidf_(logit) - r;
+                l = fmaxf(logit, 0.f) - logit * r + log1pf(__expf(-fabsf(logit)));
+            }
+            if (gl == 0) {
+                a.g_out[pos] = gk;
+                if (a.logits_out) a.logits_out[pos] = logit;
+                facc[0] = l;
+                facc[2] = gk;
+                if (a.reg_bias) sq = fmaf(pb, pb, fmaf(ob, ob, sq));
+            }
+            facc[1] = 0.5f * sq;
+        }
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             float xv = x.v[q];
@@ -490,7 +523,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) lds_t[(grp * G + gl) * VEC + q] = t.v[q];
     if (gl == 0) { lds_gb[grp] = tb; lds_key[grp] = row; }
-    __syncthreads();
+    if constexpr (FWD) block_sum_store<3, 16>(facc, a.partials + (size_t)blockIdx.x * 4);   // has the barrier
+    else __syncthreads();
     if (!pstart) return;
 
     Frag<VEC> acc = t;
@@ -993,7 +1027,7 @@ static int entry_grid(int64_t B, int G) {
     return (int)nb;
 }
 
-void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s) {
+void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipStream_t s, bool fwd) {
     int64_t B = p.a[0].B;
     if (n > 1 && p.a[1].B > B) B = p.a[1].B;
     const int epb = 1024 / G;
@@ -1002,7 +1036,9 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
     const dim3 grid((int)nb, n);
 #define TFR_RED_CASE(g, v)                                                                             \
     if (G == g && VEC == v) {                                                                          \
-        if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), grid, dim3(1024), 0, s, p); \
+        if (fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true>), grid, dim3(1024), 0, s, p); \
+        else if (fwd) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD, true>), grid, dim3(1024), 0, s, p); \
+        else if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), grid, dim3(1024), 0, s, p); \
         else if (rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM>), grid, dim3(1024), 0, s, p);  \
         else hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD>), grid, dim3(1024), 0, s, p);           \
         return;                                                                                        \
