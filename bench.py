@@ -78,8 +78,14 @@ def synth_uniform(U, I, N, seed=13575):
 def algo_bytes(kernel, B, D, U, I, adam_mode):
     if kernel == "forward":                 # 2 rows + 2 biases + 2 ids + rating + g out (+24 fused loss)
         return B * (8 * D + 24)
-    if kernel == "reduce_item":             # partner row + own row + scratch row out + g, id, pos, key
-        return B * (12 * D + 24) * (2 if B <= 16384 and U + I <= 32768 else 1)   # small tables: both sides in one launch
+    if kernel == "reduce_item":
+        small = B <= 16384 and max(U, I) <= 16384
+        if adam_mode == "lazy" and not small:
+            # big tables: forward inside the item side - P,Q,m,v rows in; w,m,v + the per-entry Q copy
+            # out; ids, position, key, rating, biases, g / logit out
+            return B * (32 * D + 48)
+        # partner row + own row + scratch row out + g, id, pos, key; small tables: both sides in one launch
+        return B * (12 * D + 24) * (2 if small else 1)
     if kernel == "reduce_user":
         if adam_mode == "lazy":             # partner row + own w,m,v read + w,m,v write + bias slots
             return B * (28 * D + 16 + 24)
