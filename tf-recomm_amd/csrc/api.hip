@@ -717,10 +717,68 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         int rc;
         tiles = tiles_eligible(m, B);
         const bool fwd_fused = fwd_in_reduce(m, B);
-        if ((rc = front_and_sort(m, du, di, dr, B, d_logits, d_store_ids, f, nblk, fin_done, tiles, fwd_fused))) return rc;
+        static int split_tiles = -1;   // TFR_TILE_SPLIT=1: the three-launch form (k_front + k_seg_reduce), kept for A/B
+        if (split_tiles < 0) { const char* e = getenv("TFR_TILE_SPLIT"); split_tiles = (e && e[0] == '1') ? 1 : 0; }
+        const bool one_launch = tiles && !split_tiles;
+        if (!one_launch)
+            if ((rc = front_and_sort(m, du, di, dr, B, d_logits, d_store_ids, f, nblk, fin_done, tiles, fwd_fused))) return rc;
         if (tiles) {
             // small tables: per-tile sorted order -> piece sums per tile -> one sweep that combines a
             // row's per-tile partials, applies the optimiser to both tables and runs K4
+            float* gp_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D;
+            if (one_launch) {
+                // gather + tile-local sort + forward + per-tile reduce of both sides: one launch
+                TileStepArgs ts;
+                memset(&ts, 0, sizeof(ts));
+                ts.P = m->w[TFR_P]; ts.Q = m->w[TFR_Q]; ts.bu = m->w[TFR_BU]; ts.bi = m->w[TFR_BI]; ts.mu = m->w[TFR_MU];
+                ts.u = du; ts.it = di; ts.r = dr;
+                if (d_store_ids) { ts.ids = d_store_ids; ts.store = m->store; }
+                ts.logits = d_logits; ts.partials = m->partials; ts.err = m->d_err;
+                ts.tab[0] = m->hist_u; ts.tab[1] = m->hist_i;
+                ts.grad_rows[0] = gp_rows; ts.grad_rows[1] = m->gq;
+                ts.grad_bias[0] = m->gbp; ts.grad_bias[1] = m->gbq;
+                ts.B = B; ts.U = m->U; ts.I = m->I; ts.N = m->N;
+                ts.D = m->D; ts.loss = o.loss; ts.item_abs = o.item_abs; ts.reg_bias = o.reg_bias;
+                ts.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+                ts.nbins[0] = 1 << m->bits_u; ts.nbins[1] = 1 << m->bits_i;
+                ts.lam = o.reg;
+                nblk = ts.ntiles * m->G;
+                f.nblk = nblk;
+                static long long* probe = nullptr; static int pcount = 0;
+                if (getenv("TFR_PROBE") && !probe) { hipMalloc(&probe, 8 * 8 * 4096); }
+                ts.probe = probe;
+                {
+                    Prof p(m, TFR_K_REDUCE_ITEM);
+                    launch_tile_step(ts, m->G, m->VEC, s);
+                }
+                HIPCHK(hipGetLastError());
+                if (probe && ++pcount == 200) {
+                    hipStreamSynchronize(s);
+                    const int nbk = ts.ntiles * m->G * 2;
+                    std::vector<long long> hp((size_t)nbk * 8);
+                    hipMemcpy(hp.data(), probe, hp.size() * 8, hipMemcpyDeviceToHost);
+                    long long t0 = hp[0];
+                    for (int b = 0; b < nbk; ++b) if (hp[(size_t)b * 8] && hp[(size_t)b * 8] < t0) t0 = hp[(size_t)b * 8];
+                    double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0}; int cntb = 0;
+                    for (int b = 0; b < nbk; ++b) {
+                        if (!hp[(size_t)b * 8 + 5]) continue;
+                        ++cntb;
+                        for (int q = 0; q < 6; ++q) { double v = (hp[(size_t)b * 8 + q] - t0) * 0.01; sum[q] += v; if (v > mx[q]) mx[q] = v; }
+                    }
+                    for (int rep = 0; rep < 6; ++rep) {
+                        int best = -1; long long bt = 0;
+                        for (int b = 0; b < nbk; ++b) if (hp[(size_t)b * 8 + 5] > bt) { bt = hp[(size_t)b * 8 + 5]; best = b; }
+                        if (best < 0) break;
+                        const int per = ts.ntiles * m->G;
+                        fprintf(stderr, "PROBE slow block side=%d tile=%d slice=%d:", best / per, (best % per) / m->G, best % m->G);
+                        for (int q = 0; q < 6; ++q) fprintf(stderr, " %.2f", (hp[(size_t)best * 8 + q] - t0) * 0.01);
+                        fprintf(stderr, "\n");
+                        hp[(size_t)best * 8 + 5] = 0;
+                    }
+                    fprintf(stderr, "PROBE blocks=%d (us since first block start) mean/max: start %.2f/%.2f gathered %.2f/%.2f turns %.2f/%.2f sorted %.2f/%.2f contrib %.2f/%.2f end %.2f/%.2f\n",
+                            cntb, sum[0] / cntb, mx[0], sum[1] / cntb, mx[1], sum[2] / cntb, mx[2], sum[3] / cntb, mx[3], sum[4] / cntb, mx[4], sum[5] / cntb, mx[5]);
+                }
+            }
             RedArgs r;
             memset(&r, 0, sizeof(r));
             r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D; r.tile = CSORT_TILE;
@@ -733,8 +791,8 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             pr.a[1] = r;
             pr.a[1].side = 0; pr.a[1].ks = m->ks_u; pr.a[1].ps = m->ps_u; pr.a[1].other = di;
             pr.a[1].own = m->w[TFR_P]; pr.a[1].partner = m->w[TFR_Q]; pr.a[1].own_bias = m->w[TFR_BU];
-            pr.a[1].grad_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D; pr.a[1].grad_bias = m->gbp;
-            {
+            pr.a[1].grad_rows = gp_rows; pr.a[1].grad_bias = m->gbp;
+            if (!one_launch) {
                 Prof p(m, TFR_K_REDUCE_ITEM);
                 launch_seg_reduce(pr, 2, RMODE_SCRATCH, m->G, m->VEC, s);
             }

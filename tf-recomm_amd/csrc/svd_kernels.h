@@ -139,6 +139,24 @@ struct FrontArgs {
     int32_t tile_local;          // 1: sort each tile locally (hist / offs become per-tile lookup tables)
 };
 
+// small tables, whole step before the optimiser in ONE launch (k_tile_step): gather + tile-local
+// sort + forward + per-tile segmented reduce, for both id columns
+struct TileStepArgs {
+    const float* P; const float* Q; const float* bu; const float* bi; const float* mu;
+    const int32_t* u; const int32_t* it; const float* r;    // the batch, or (ids != NULL) rows of the store
+    const int64_t* ids; const int4* store;
+    float* logits;                                           // optional [B]
+    float* partials;                                         // [ntiles * G][4]: {loss, reg, sum g, -}
+    int32_t* err;
+    int32_t* tab[2];                                         // [ntiles * nbins[c]] packed (count << 16) | offset
+    float* grad_rows[2]; float* grad_bias[2];                // piece sums by tile-sorted position; 0 = user side
+    int64_t B, U, I, N;
+    int32_t D, loss, item_abs, reg_bias, ntiles, nbins[2];
+    float lam;
+    long long* probe;
+};
+void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s);
+
 // row geometry for a dim: returns false if unsupported
 inline bool geometry(int D, int* G, int* VEC) {
     if (D < 1) return false;

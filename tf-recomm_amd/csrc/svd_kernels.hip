@@ -251,6 +251,33 @@ __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
     forward_body<G, VEC, MODE, UNR, 4>(a, blockIdx.x, gridDim.x);
 }
 
+// In-LDS exclusive scan of a tile's nb bin counts into the packed form (count << 16) | start.
+// Thread t owns bins t, t + 1024, ... (bank-conflict free) and those bins are CONSECUTIVE in the
+// tile's sorted order (order index of bin q * 1024 + t is t * per + q): equal ids stay contiguous,
+// which is all the reduce and the sweep need - the order of distinct ids inside a tile is free.
+// wtot: 16 ints of scratch.  All 1024 threads call; ends with a barrier.  nb <= 16384.
+__device__ __forceinline__ void tile_scan_pack(int32_t* cnt, int nb, int32_t* wtot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nb + 1023) / 1024;                  // <= 16
+    int32_t sum = 0;
+    for (int q = 0; q < per; ++q) { const int b = q * 1024 + tid; if (b < nb) sum += cnt[b]; }
+    int32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t2 = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t2;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+    for (int q = 0; q < per; ++q) {
+        const int b = q * 1024 + tid;
+        if (b < nb) { const int32_t c2 = cnt[b]; cnt[b] = (c2 << 16) | run; run += c2; }
+    }
+    __syncthreads();
+}
+
 // Small-table training: the forward and the counting sort's rank pass do not depend on each other,
 // so they share one launch - blocks [0, nfwd) run the forward (16 waves each), the rest rank one
 // (tile, column) each.  In fused-gather mode the rank blocks read the store records themselves and
@@ -308,31 +335,199 @@ __global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
     // tile-local sort: the tile's entries are put in key order right here (no global scan / scatter
     // launches).  hist[tile][bin] = (entries of the tile with that key) << 16 | (where they start inside
     // the tile's sorted list); the sweep finds a row's per-tile runs through this table.
-    __shared__ int32_t wtot[CSORT_TILE / 64];
-    const int per = (nb + CSORT_TILE - 1) / CSORT_TILE;          // bins per thread, contiguous
-    int32_t sum = 0;
-    for (int q = 0; q < per; ++q) { const int b = tid * per + q; if (b < nb) sum += cnt[b]; }
-    int32_t incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    int32_t run = incl - sum;
-    for (int w = 0; w < wave; ++w) run += wtot[w];
-    for (int q = 0; q < per; ++q) {                               // in place: (count << 16) | start offset
-        const int b = tid * per + q;
-        if (b < nb) { const int32_t c2 = cnt[b]; cnt[b] = (c2 << 16) | run; run += c2; }
-    }
-    __syncthreads();
+    __shared__ int32_t wtot[256];
+    tile_scan_pack(cnt, nb, wtot);
     for (int b = tid; b < nb; b += CSORT_TILE) a.hist[col][(size_t)tile * nb + b] = cnt[b];     // packed lookup table
     if (valid) {
         const int64_t dst = (int64_t)tile * CSORT_TILE + (cnt[key] & 0xffff) + base + rank_in_wave;
         a.ks[col][dst] = fullkey;
         a.ps[col][dst] = (int32_t)k;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// K1+K2+K3 for small tables in one launch.  grid = (ntiles * G, 2): block (tile, slice, side).
+// Every block of a tile repeats the tile's gather and its stable counting sort by the side's id
+// column (1024 entries, all in LDS: ballot ranks, ordered wave turns, in-LDS scan - cheap next to a
+// launch and three dependent memory round trips), then owns slice = 1024/G consecutive entries of
+// the tile's sorted list: one lane group per entry loads P[u], Q[i] once, forms the logit and
+// g = dcost/dlogit exactly as K1 does (both sides compute the same g from the same registers), its
+// contribution goes to LDS and the run heads add their runs in entry order (K3).  Piece sums land at
+// the tile-sorted position; slice 0 publishes the tile's packed lookup table for k_dense_tiles.
+// The item side also writes the logits and the per-block {loss, reg, sum g}.
+template <int G, int VEC>
+__global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a) {
+    constexpr int EPB = 1024 / G;
+    extern __shared__ int32_t dyn[];                     // sort: cnt[nbins]; then the contributions
+    __shared__ int32_t rec_u[1024], rec_i[1024], srt_key[1024], srt_pos[1024];
+    __shared__ float rec_r[1024];
+    __shared__ float lds_gb[2 * EPB];
+    __shared__ int32_t lds_key[EPB];
+    __shared__ int32_t wtot[256];
+    const int side = blockIdx.y;                         // 0: user rows, 1: item rows
+    long long* pb = a.probe ? a.probe + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    if (pb && threadIdx.x == 0) pb[0] = wall_clock64();
+    const int tile = blockIdx.x / G, slice = blockIdx.x % G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tile0 = (int64_t)tile * 1024;
+    const int nvalid = (a.B - tile0 < 1024) ? (int)(a.B - tile0) : 1024;
+    if (slice * EPB >= nvalid) {                         // a short last tile: nothing in this slice
+        if (side == 1 && tid < 4) a.partials[(size_t)blockIdx.x * 4 + tid] = 0.f;
+        return;
+    }
+    // ---- gather the tile (dataio.py:115-117 when fused) and range-check the ids
+    const int nb = a.nbins[side];
+    int32_t* cnt = dyn;
+    for (int b = tid; b < nb; b += 1024) cnt[b] = 0;
+    const bool valid = tid < nvalid;
+    int32_t u = 0, it = 0;
+    float r = 0.f;
+    if (valid) {
+        const int64_t k = tile0 + tid;
+        bool oob = false;
+        if (a.ids) {
+            int64_t id = a.ids[k];
+            if ((uint64_t)id >= (uint64_t)a.N) { atomicOr(a.err, 2); id = 0; }
+            const int4 rec = a.store[id];
+            u = rec.x; it = rec.y; r = __int_as_float(rec.z);
+        } else {
+            u = a.u[k]; it = a.it[k]; r = a.r[k];
+        }
+        if ((uint64_t)(int64_t)u >= (uint64_t)a.U) { oob = true; u = 0; }
+        if ((uint64_t)(int64_t)it >= (uint64_t)a.I) { oob = true; it = 0; }
+        if (oob) atomicOr(a.err, 1);
+    }
+    rec_u[tid] = u; rec_i[tid] = it; rec_r[tid] = r;
+    __syncthreads();
+    if (pb && tid == 0) pb[1] = wall_clock64();
+    // ---- stable counting sort of the tile by this side's id
+    const int32_t key = side == 0 ? u : it;
+    unsigned long long mask = __ballot(valid);
+    for (int bit = 1; bit < nb; bit <<= 1) {
+        const unsigned long long mm = __ballot((key & bit) != 0);
+        mask &= (key & bit) ? mm : ~mm;
+    }
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    const int rank_in_wave = __popcll(below);
+    const int group_size = __popcll(mask);
+    int base = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (wave == w && valid) {
+            base = cnt[key];
+            if (below == 0) cnt[key] = base + group_size;
+        }
+        __syncthreads();
+    }
+    if (pb && tid == 0) pb[2] = wall_clock64();
+    tile_scan_pack(cnt, nb, wtot);
+    {   // the tile's packed lookup table, written once: its bins are dealt round the tile's active slices
+        const int nact = (nvalid + EPB - 1) / EPB;
+        for (int b = slice * 1024 + tid; b < nb; b += nact * 1024) a.tab[side][(size_t)tile * nb + b] = cnt[b];
+    }
+    if (valid) {
+        const int dst = (cnt[key] & 0xffff) + base + rank_in_wave;
+        srt_key[dst] = key;
+        srt_pos[dst] = tid;
+    }
+    __syncthreads();                                     // cnt is dead from here: its memory takes the contributions
+    if (pb && tid == 0) pb[3] = wall_clock64();
+    float* lds_t = reinterpret_cast<float*>(dyn);
+
+    // ---- this slice's entries: forward + contribution
+    const int grp = tid / G, gl = tid % G, d0 = gl * VEC;
+    const int D = a.D;
+    const int jl = slice * EPB + grp;
+    const bool ev = jl < nvalid;
+    int32_t row = -1, prev = -2, pl = 0;
+    if (ev) {
+        row = srt_key[jl];
+        prev = (jl > 0) ? srt_key[jl - 1] : -2;
+        pl = srt_pos[jl];
+    }
+    const bool head = ev && prev != row;                 // jl == 0: the sorted order restarts with the tile
+    const bool pstart = ev && (head || grp == 0);
+    Frag<VEC> t;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) t.v[q] = 0.f;
+    float tb = 0.f;
+    float facc[3] = {0.f, 0.f, 0.f};
+    if (ev) {
+        const int32_t uu = rec_u[pl], ii = rec_i[pl];
+        const float rr = rec_r[pl];
+        const Frag<VEC> p = load_frag<VEC>(a.P + (size_t)uu * D, d0, D);
+        const Frag<VEC> q = load_frag<VEC>(a.Q + (size_t)ii * D, d0, D);
+        const float bu_ = a.bu[uu], bi_ = a.bi[ii];
+        float sdot = 0.f, sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float qv = q.v[e];
+            sdot = fmaf(p.v[e], a.item_abs ? fabsf(qv) : qv, sdot);
+            sq = fmaf(p.v[e], p.v[e], fmaf(qv, qv, sq));
+        }
+        sdot = group_sum<G>(sdot);
+        const float logit = ((sdot + *a.mu) + bu_) + bi_;          // ops.py:45-47 order
+        float gk, l;
+        if (a.loss == 0) {                               // ops.py:124
+            gk = logit - rr;
+            l = 0.5f * gk * gk;
+        } else {                                         // ops.py:125-126
+            gk = sigmoidf_(logit) - rr;
+            l = fmaxf(logit, 0.f) - logit * rr + log1pf(__expf(-fabsf(logit)));
+        }
+        if (side == 1) {
+            if (gl == 0) {
+                if (a.logits) a.logits[tile0 + pl] = logit;
+                facc[0] = l;
+                facc[2] = gk;
+                if (a.reg_bias) sq = fmaf(bu_, bu_, fmaf(bi_, bi_, sq));
+            }
+            facc[1] = 0.5f * sq;                         // tf.nn.l2_loss = sum(x^2)/2
+        }
+        const float ob = side == 0 ? bu_ : bi_;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float ov = side == 0 ? p.v[e] : q.v[e];
+            float xv = side == 0 ? q.v[e] : p.v[e];
+            if (side == 0) { if (a.item_abs) xv = fabsf(xv); }
+            else if (a.item_abs) xv = xv * ((ov > 0.f) ? 1.f : ((ov < 0.f) ? -1.f : 0.f));
+            t.v[e] = gk * xv + a.lam * ov;
+        }
+        tb = a.reg_bias ? (gk + a.lam * ob) : gk;
+    }
+    // ---- K3 inside the slice: suffix sums within runs by doubling (log2 EPB rounds, ping-pong in
+    //      LDS).  After round d a group holds the sum of its next 2d entries of the same run; the fixed
+    //      tree order keeps results bit-identical run to run however long the runs are.
+    float* bufv[2] = {lds_t, lds_t + 1024 * VEC};
+    float* bufb[2] = {lds_gb, lds_gb + EPB};
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) bufv[0][(grp * G + gl) * VEC + q] = t.v[q];
+    if (gl == 0) { bufb[0][grp] = tb; lds_key[grp] = row; }
+    if (side == 1) block_sum_store<3, 16>(facc, a.partials + (size_t)blockIdx.x * 4);   // has the barrier
+    else __syncthreads();
+    if (pb && tid == 0) pb[4] = wall_clock64();
+    Frag<VEC> acc = t;
+    float gb = tb;
+    int cur = 0;
+#pragma unroll
+    for (int d = 1; d < EPB; d <<= 1) {
+        const int e2 = grp + d;
+        const bool take = ev && e2 < EPB && lds_key[e2] == row;
+        if (take) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc.v[q] += bufv[cur][(e2 * G + gl) * VEC + q];
+            gb += bufb[cur][e2];
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) bufv[cur ^ 1][(grp * G + gl) * VEC + q] = acc.v[q];
+        if (gl == 0) bufb[cur ^ 1][grp] = gb;
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (!pstart) return;
+    const int64_t j = tile0 + jl;
+    store_frag<VEC>(a.grad_rows[side] + (size_t)j * D, d0, D, acc);
+    if (gl == 0) a.grad_bias[side][j] = gb;
+    if (pb && tid == 0) pb[5] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------
@@ -1012,6 +1207,27 @@ void launch_front(const FrontArgs& fa, int G, int VEC, hipStream_t s) {
     TFR_FRONT_CASE(4, 4) TFR_FRONT_CASE(8, 4) TFR_FRONT_CASE(16, 4) TFR_FRONT_CASE(32, 4) TFR_FRONT_CASE(64, 4)
     TFR_FRONT_CASE(4, 1) TFR_FRONT_CASE(8, 1) TFR_FRONT_CASE(16, 1) TFR_FRONT_CASE(32, 1) TFR_FRONT_CASE(64, 1)
 #undef TFR_FRONT_CASE
+}
+
+void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s) {
+    const int nbmax = a.nbins[0] > a.nbins[1] ? a.nbins[0] : a.nbins[1];
+    size_t dyn = (size_t)nbmax * 4;                       // bins during the sort, contributions afterwards
+    if (dyn < (size_t)2 * 1024 * VEC * 4) dyn = (size_t)2 * 1024 * VEC * 4;     // ping-pong buffers of the in-slice reduce
+    const dim3 grid(a.ntiles * G, 2);
+#define TFR_TS_CASE(g, v)                                                                             \
+    if (G == g && VEC == v) {                                                                         \
+        static bool attr = false;                                                                     \
+        if (!attr) {                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_step<g, v>),               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, CSORT_MAX_BINS * 4); \
+            attr = true;                                                                              \
+        }                                                                                             \
+        hipLaunchKernelGGL((k_tile_step<g, v>), grid, dim3(1024), dyn, s, a);                         \
+        return;                                                                                       \
+    }
+    TFR_TS_CASE(4, 4) TFR_TS_CASE(8, 4) TFR_TS_CASE(16, 4) TFR_TS_CASE(32, 4) TFR_TS_CASE(64, 4)
+    TFR_TS_CASE(4, 1) TFR_TS_CASE(8, 1) TFR_TS_CASE(16, 1) TFR_TS_CASE(32, 1) TFR_TS_CASE(64, 1)
+#undef TFR_TS_CASE
 }
 
 void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s) {
