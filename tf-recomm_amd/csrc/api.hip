@@ -69,6 +69,9 @@ struct tfr_model {
     float* step_out = nullptr;        // per-step {loss, reg, sum_g} ring for multi-step calls
     int64_t step_out_cap = 0;
     int32_t* d_err = nullptr;
+    // look-ahead of the small-table step: the next batch's tile sort, published by the previous launch
+    int4* srt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [parity][side] sorted records {u, i, r, pos}
+    const int64_t* pf_ids = nullptr; int64_t pf_B = 0; int pf_par = 0; bool pf_valid = false;
     // resident store
     int4* store = nullptr;            // {user, item, rate bits, -} per rating
     int64_t N = 0;
@@ -148,6 +151,8 @@ static void free_workspace(tfr_model* m) {
     dfree(m->partials); dfree(m->lrank_u); dfree(m->lrank_i); dfree(m->hist_u); dfree(m->hist_i);
     dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
     dfree(m->blocktot_u); dfree(m->blocktot_i);
+    for (int pz = 0; pz < 2; ++pz) for (int sd = 0; sd < 2; ++sd) { dfree(m->srt[pz][sd]); m->srt[pz][sd] = nullptr; }
+    m->pf_valid = false;
     m->blocktot_u = m->blocktot_i = nullptr;
     m->lrank_u = m->lrank_i = m->hist_u = m->hist_i = nullptr;
     m->offs_u = m->offs_i = m->binbase_u = m->binbase_i = nullptr;
@@ -183,6 +188,10 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     // per-entry copies of pre-update item rows the fused user side reads
     if ((rc = dmalloc(&m->gq, (size_t)cap * m->D * (tf1_ws ? 1 : 3)))) return rc;
     if ((rc = dmalloc(&m->gbq, cap))) return rc;
+    for (int pz = 0; pz < 2; ++pz)
+        for (int sd = 0; sd < 2; ++sd)
+            if ((rc = dmalloc(&m->srt[pz][sd], cap))) return rc;
+    m->pf_valid = false;
     if ((rc = dmalloc(&m->gbp, cap))) return rc;
     if (tf1_ws)
         if ((rc = dmalloc(&m->gp, (size_t)cap * m->D))) return rc;
@@ -698,7 +707,8 @@ static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, 
 // one minibatch on device-resident (u, i, r) - or, with d_store_ids, on rows of the resident
 // store gathered inside the forward kernel; out3 = optional device {loss, reg, sum_g} slot
 static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
-                          float* d_logits, float* out3, const int64_t* d_store_ids = nullptr) {
+                          float* d_logits, float* out3, const int64_t* d_store_ids = nullptr,
+                          const int64_t* next_store_ids = nullptr) {
     const tfr_opts& o = m->o;
     const bool adam = o.optimizer == TFR_OPT_ADAM;
     const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
@@ -726,6 +736,7 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             // small tables: per-tile sorted order -> piece sums per tile -> one sweep that combines a
             // row's per-tile partials, applies the optimiser to both tables and runs K4
             float* gp_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D;
+            int par = 0;
             if (one_launch) {
                 // gather + tile-local sort + forward + per-tile reduce of both sides: one launch
                 TileStepArgs ts;
@@ -734,7 +745,22 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
                 ts.u = du; ts.it = di; ts.r = dr;
                 if (d_store_ids) { ts.ids = d_store_ids; ts.store = m->store; }
                 ts.logits = d_logits; ts.partials = m->partials; ts.err = m->d_err;
-                ts.tab[0] = m->hist_u; ts.tab[1] = m->hist_i;
+                // look-ahead (multi-step calls on the resident store): was this batch's tile sort published by
+                // the previous launch?  Is there a next batch to sort in this one?  The packed tables and the
+                // sorted records are double-buffered by step parity (hist_* / offs_* serve as the two tables).
+                const bool presorted = m->pf_valid && d_store_ids && m->pf_ids == d_store_ids && m->pf_B == B;
+                par = presorted ? m->pf_par : 0;
+                int32_t* tabs[2][2] = {{m->hist_u, m->hist_i}, {m->offs_u, m->offs_i}};
+                ts.tab[0] = tabs[par][0]; ts.tab[1] = tabs[par][1];
+                if (presorted) { ts.srt[0] = m->srt[par][0]; ts.srt[1] = m->srt[par][1]; }
+                m->pf_valid = false;
+                if (next_store_ids && d_store_ids) {
+                    ts.store = m->store;
+                    ts.next_ids = next_store_ids; ts.next_B = B; ts.next_ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+                    ts.next_tab[0] = tabs[par ^ 1][0]; ts.next_tab[1] = tabs[par ^ 1][1];
+                    ts.next_srt[0] = m->srt[par ^ 1][0]; ts.next_srt[1] = m->srt[par ^ 1][1];
+                    m->pf_valid = true; m->pf_ids = next_store_ids; m->pf_B = B; m->pf_par = par ^ 1;
+                }
                 ts.grad_rows[0] = gp_rows; ts.grad_rows[1] = m->gq;
                 ts.grad_bias[0] = m->gbp; ts.grad_bias[1] = m->gbq;
                 ts.B = B; ts.U = m->U; ts.I = m->I; ts.N = m->N;
@@ -742,42 +768,13 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
                 ts.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
                 ts.nbins[0] = 1 << m->bits_u; ts.nbins[1] = 1 << m->bits_i;
                 ts.lam = o.reg;
-                nblk = ts.ntiles * m->G;
+                nblk = ts.ntiles * (m->G / tile_step_epg(ts.ntiles, m->G, m->VEC));
                 f.nblk = nblk;
-                static long long* probe = nullptr; static int pcount = 0;
-                if (getenv("TFR_PROBE") && !probe) { hipMalloc(&probe, 8 * 8 * 4096); }
-                ts.probe = probe;
                 {
                     Prof p(m, TFR_K_REDUCE_ITEM);
                     launch_tile_step(ts, m->G, m->VEC, s);
                 }
                 HIPCHK(hipGetLastError());
-                if (probe && ++pcount == 200) {
-                    hipStreamSynchronize(s);
-                    const int nbk = ts.ntiles * m->G * 2;
-                    std::vector<long long> hp((size_t)nbk * 8);
-                    hipMemcpy(hp.data(), probe, hp.size() * 8, hipMemcpyDeviceToHost);
-                    long long t0 = hp[0];
-                    for (int b = 0; b < nbk; ++b) if (hp[(size_t)b * 8] && hp[(size_t)b * 8] < t0) t0 = hp[(size_t)b * 8];
-                    double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0}; int cntb = 0;
-                    for (int b = 0; b < nbk; ++b) {
-                        if (!hp[(size_t)b * 8 + 5]) continue;
-                        ++cntb;
-                        for (int q = 0; q < 6; ++q) { double v = (hp[(size_t)b * 8 + q] - t0) * 0.01; sum[q] += v; if (v > mx[q]) mx[q] = v; }
-                    }
-                    for (int rep = 0; rep < 6; ++rep) {
-                        int best = -1; long long bt = 0;
-                        for (int b = 0; b < nbk; ++b) if (hp[(size_t)b * 8 + 5] > bt) { bt = hp[(size_t)b * 8 + 5]; best = b; }
-                        if (best < 0) break;
-                        const int per = ts.ntiles * m->G;
-                        fprintf(stderr, "PROBE slow block side=%d tile=%d slice=%d:", best / per, (best % per) / m->G, best % m->G);
-                        for (int q = 0; q < 6; ++q) fprintf(stderr, " %.2f", (hp[(size_t)best * 8 + q] - t0) * 0.01);
-                        fprintf(stderr, "\n");
-                        hp[(size_t)best * 8 + 5] = 0;
-                    }
-                    fprintf(stderr, "PROBE blocks=%d (us since first block start) mean/max: start %.2f/%.2f gathered %.2f/%.2f turns %.2f/%.2f sorted %.2f/%.2f contrib %.2f/%.2f end %.2f/%.2f\n",
-                            cntb, sum[0] / cntb, mx[0], sum[1] / cntb, mx[1], sum[2] / cntb, mx[2], sum[3] / cntb, mx[3], sum[4] / cntb, mx[4], sum[5] / cntb, mx[5]);
-                }
             }
             RedArgs r;
             memset(&r, 0, sizeof(r));
@@ -805,13 +802,13 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             d.opt = adam ? 0 : 1; d.skip_untouched = tf1 ? 0 : 1;
             d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps; d.lr = o.lr;
             L.a[0] = d;                // items
-            L.a[0].tab = m->hist_i; L.a[0].nbins = 1 << m->bits_i; L.a[0].rows = m->I;
+            L.a[0].tab = par ? m->offs_i : m->hist_i; L.a[0].nbins = 1 << m->bits_i; L.a[0].rows = m->I;
             L.a[0].grad_rows = m->gq; L.a[0].grad_bias = m->gbq;
             L.a[0].w = m->w[TFR_Q]; L.a[0].m = m->m[TFR_Q]; L.a[0].v = m->v[TFR_Q];
             L.a[0].bias_w = m->w[TFR_BI]; L.a[0].bias_m = m->m[TFR_BI]; L.a[0].bias_v = m->v[TFR_BI];
             L.a[0].frozen_rows = (m->frozen >> TFR_Q) & 1; L.a[0].frozen_bias = (m->frozen >> TFR_BI) & 1;
             L.a[1] = d;                // users
-            L.a[1].tab = m->hist_u; L.a[1].nbins = 1 << m->bits_u; L.a[1].rows = m->U;
+            L.a[1].tab = par ? m->offs_u : m->hist_u; L.a[1].nbins = 1 << m->bits_u; L.a[1].rows = m->U;
             L.a[1].grad_rows = pr.a[1].grad_rows; L.a[1].grad_bias = m->gbp;
             L.a[1].w = m->w[TFR_P]; L.a[1].m = m->m[TFR_P]; L.a[1].v = m->v[TFR_P];
             L.a[1].bias_w = m->w[TFR_BU]; L.a[1].bias_m = m->m[TFR_BU]; L.a[1].bias_v = m->v[TFR_BU];
@@ -1093,7 +1090,7 @@ int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float
 static int build_store(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t N, bool on_device) {
     HIPCHK(hipStreamSynchronize(m->stream));
     dfree(m->store);
-    m->store = nullptr; m->N = 0;
+    m->store = nullptr; m->N = 0; m->pf_valid = false;
     int rc;
     if ((rc = dmalloc(&m->store, (size_t)N))) return rc;
     if (on_device) {
@@ -1164,7 +1161,7 @@ int tfr_stage_ids(tfr_model* m, const int64_t* ids, int64_t n) {
     if (n < 1 || !ids) return fail(TFR_ERR_ARG, "stage_ids: need n >= 1 and non-null ids");
     HIPCHK(hipStreamSynchronize(m->stream));
     dfree(m->d_ids);
-    m->d_ids = nullptr; m->n_ids = 0;
+    m->d_ids = nullptr; m->n_ids = 0; m->pf_valid = false;
     int rc;
     if ((rc = dmalloc(&m->d_ids, (size_t)n))) return rc;
     HIPCHK(hipMemcpyAsync(m->d_ids, ids, (size_t)n * 8, hipMemcpyHostToDevice, m->stream));
@@ -1195,14 +1192,18 @@ static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nst
     for (int32_t s = 0; s < nsteps; ++s) {
         if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr,
                                  loss_out ? m->step_out + (size_t)s * 4 : nullptr,
-                                 m->d_ids + (first_step + s) * B)))
+                                 m->d_ids + (first_step + s) * B,
+                                 s + 1 < nsteps ? m->d_ids + (first_step + s + 1) * B : nullptr))) {
+            m->pf_valid = false;
             return rc;
+        }
     }
     if (loss_out) {
         std::vector<float> tmp((size_t)nsteps * 4);
         HIPCHK(hipMemcpyAsync(tmp.data(), m->step_out, tmp.size() * 4, hipMemcpyDeviceToHost, m->stream));
         if ((rc = check_device_error(m))) {
             rollback_step(m, step0, b1p0, b2p0);
+            m->pf_valid = false;
             return rc;
         }
         for (int32_t s = 0; s < nsteps; ++s) loss_out[s] = tmp[(size_t)s * 4];

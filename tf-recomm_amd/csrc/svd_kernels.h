@@ -101,7 +101,7 @@ struct TileDenseArgs {
     int32_t D, nbins, ntiles, frozen_rows, frozen_bias, opt, skip_untouched;
     float alpha, b1, b2, eps, lr;
 };
-struct TileDenseLaunch { TileDenseArgs a[2]; FinArgs f; };
+struct TileDenseLaunch { TileDenseArgs a[2]; FinArgs f; int32_t with_fin; };
 void launch_dense_tiles(const TileDenseLaunch& L, bool write, bool with_fin, int G, int VEC, hipStream_t s);
 
 // one-pass stable counting sort of both id columns (small tables: all bins fit in LDS)
@@ -145,17 +145,22 @@ struct TileStepArgs {
     const float* P; const float* Q; const float* bu; const float* bi; const float* mu;
     const int32_t* u; const int32_t* it; const float* r;    // the batch, or (ids != NULL) rows of the store
     const int64_t* ids; const int4* store;
+    const int4* srt[2];                                      // non-NULL: this batch's tile-sorted records {u, i, r, pos},
+                                                             // published by the previous step's launch (then u/it/r/ids unused)
     float* logits;                                           // optional [B]
-    float* partials;                                         // [ntiles * G][4]: {loss, reg, sum g, -}
+    float* partials;                                         // [ntiles * G / EPG][4]: {loss, reg, sum g, -}
     int32_t* err;
     int32_t* tab[2];                                         // [ntiles * nbins[c]] packed (count << 16) | offset
     float* grad_rows[2]; float* grad_bias[2];                // piece sums by tile-sorted position; 0 = user side
     int64_t B, U, I, N;
     int32_t D, loss, item_abs, reg_bias, ntiles, nbins[2];
     float lam;
-    long long* probe;
+    // look-ahead: sort the NEXT batch (rows next_ids[0..next_B) of the store) in spare blocks of this launch
+    const int64_t* next_ids; int64_t next_B; int32_t next_ntiles;
+    int32_t* next_tab[2]; int4* next_srt[2];
 };
 void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s);
+int tile_step_epg(int ntiles, int G, int VEC);       // pieces per block k_tile_step will use (grid = ntiles * G / epg per side)
 
 // row geometry for a dim: returns false if unsupported
 inline bool geometry(int D, int* G, int* VEC) {

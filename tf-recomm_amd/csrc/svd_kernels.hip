@@ -346,61 +346,44 @@ __global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
 }
 
 // ------------------------------------------------------------------------------------
-// K1+K2+K3 for small tables in one launch.  grid = (ntiles * G, 2): block (tile, slice, side).
-// Every block of a tile repeats the tile's gather and its stable counting sort by the side's id
-// column (1024 entries, all in LDS: ballot ranks, ordered wave turns, in-LDS scan - cheap next to a
-// launch and three dependent memory round trips), then owns slice = 1024/G consecutive entries of
-// the tile's sorted list: one lane group per entry loads P[u], Q[i] once, forms the logit and
-// g = dcost/dlogit exactly as K1 does (both sides compute the same g from the same registers), its
-// contribution goes to LDS and the run heads add their runs in entry order (K3).  Piece sums land at
-// the tile-sorted position; slice 0 publishes the tile's packed lookup table for k_dense_tiles.
-// The item side also writes the logits and the per-block {loss, reg, sum g}.
-template <int G, int VEC>
-__global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a) {
-    constexpr int EPB = 1024 / G;
-    extern __shared__ int32_t dyn[];                     // sort: cnt[nbins]; then the contributions
-    __shared__ int32_t rec_u[1024], rec_i[1024], srt_key[1024], srt_pos[1024];
-    __shared__ float rec_r[1024];
-    __shared__ float lds_gb[2 * EPB];
-    __shared__ int32_t lds_key[EPB];
-    __shared__ int32_t wtot[256];
-    const int side = blockIdx.y;                         // 0: user rows, 1: item rows
-    long long* pb = a.probe ? a.probe + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
-    if (pb && threadIdx.x == 0) pb[0] = wall_clock64();
-    const int tile = blockIdx.x / G, slice = blockIdx.x % G;
+// K1+K2+K3 for small tables in one launch (k_tile_step).
+//
+// tile_sort: one 1024-thread block gathers a 1024-entry tile of a batch (dataio.py:115-117 when the
+// ids index the resident store), range-checks the ids and sorts the tile by one id column with a
+// stable counting sort held entirely in LDS (ballot ranks, ordered wave turns, in-LDS scan).  On
+// return cnt[] holds the packed lookup table, srt_key / srt_pos the sorted order, rec_* the tile's
+// records by batch position.  Ends with a barrier.
+struct TileLds {
+    int32_t* cnt; int32_t* rec_u; int32_t* rec_i; float* rec_r; int32_t* srt_key; int32_t* srt_pos; int32_t* wtot;
+};
+__device__ __forceinline__ void tile_sort(int32_t* cnt_, int32_t* rec_u_, int32_t* rec_i_, float* rec_r_, int32_t* srt_key_,
+                                          int32_t* srt_pos_, int32_t* wtot_, const int64_t* ids, const int4* store, const int32_t* bu_,
+                                          const int32_t* bi_, const float* br_, int64_t tile0, int nvalid, int side, int nb,
+                                          int64_t N, int64_t U, int64_t I, int32_t* err) {
+    TileLds L;
+    L.cnt = cnt_; L.rec_u = rec_u_; L.rec_i = rec_i_; L.rec_r = rec_r_; L.srt_key = srt_key_; L.srt_pos = srt_pos_; L.wtot = wtot_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t tile0 = (int64_t)tile * 1024;
-    const int nvalid = (a.B - tile0 < 1024) ? (int)(a.B - tile0) : 1024;
-    if (slice * EPB >= nvalid) {                         // a short last tile: nothing in this slice
-        if (side == 1 && tid < 4) a.partials[(size_t)blockIdx.x * 4 + tid] = 0.f;
-        return;
-    }
-    // ---- gather the tile (dataio.py:115-117 when fused) and range-check the ids
-    const int nb = a.nbins[side];
-    int32_t* cnt = dyn;
-    for (int b = tid; b < nb; b += 1024) cnt[b] = 0;
+    for (int b = tid; b < nb; b += 1024) L.cnt[b] = 0;
     const bool valid = tid < nvalid;
     int32_t u = 0, it = 0;
     float r = 0.f;
     if (valid) {
         const int64_t k = tile0 + tid;
         bool oob = false;
-        if (a.ids) {
-            int64_t id = a.ids[k];
-            if ((uint64_t)id >= (uint64_t)a.N) { atomicOr(a.err, 2); id = 0; }
-            const int4 rec = a.store[id];
+        if (ids) {
+            int64_t id = ids[k];
+            if ((uint64_t)id >= (uint64_t)N) { atomicOr(err, 2); id = 0; }
+            const int4 rec = store[id];
             u = rec.x; it = rec.y; r = __int_as_float(rec.z);
         } else {
-            u = a.u[k]; it = a.it[k]; r = a.r[k];
+            u = bu_[k]; it = bi_[k]; r = br_[k];
         }
-        if ((uint64_t)(int64_t)u >= (uint64_t)a.U) { oob = true; u = 0; }
-        if ((uint64_t)(int64_t)it >= (uint64_t)a.I) { oob = true; it = 0; }
-        if (oob) atomicOr(a.err, 1);
+        if ((uint64_t)(int64_t)u >= (uint64_t)U) { oob = true; u = 0; }
+        if ((uint64_t)(int64_t)it >= (uint64_t)I) { oob = true; it = 0; }
+        if (oob) atomicOr(err, 1);
     }
-    rec_u[tid] = u; rec_i[tid] = it; rec_r[tid] = r;
+    L.rec_u[tid] = u; L.rec_i[tid] = it; L.rec_r[tid] = r;
     __syncthreads();
-    if (pb && tid == 0) pb[1] = wall_clock64();
-    // ---- stable counting sort of the tile by this side's id
     const int32_t key = side == 0 ? u : it;
     unsigned long long mask = __ballot(valid);
     for (int bit = 1; bit < nb; bit <<= 1) {
@@ -413,121 +396,214 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a) {
     int base = 0;
     for (int w = 0; w < 16; ++w) {
         if (wave == w && valid) {
-            base = cnt[key];
-            if (below == 0) cnt[key] = base + group_size;
+            base = L.cnt[key];
+            if (below == 0) L.cnt[key] = base + group_size;
         }
         __syncthreads();
     }
-    if (pb && tid == 0) pb[2] = wall_clock64();
-    tile_scan_pack(cnt, nb, wtot);
-    {   // the tile's packed lookup table, written once: its bins are dealt round the tile's active slices
-        const int nact = (nvalid + EPB - 1) / EPB;
-        for (int b = slice * 1024 + tid; b < nb; b += nact * 1024) a.tab[side][(size_t)tile * nb + b] = cnt[b];
-    }
+    tile_scan_pack(L.cnt, nb, L.wtot);
     if (valid) {
-        const int dst = (cnt[key] & 0xffff) + base + rank_in_wave;
-        srt_key[dst] = key;
-        srt_pos[dst] = tid;
+        const int dst = (L.cnt[key] & 0xffff) + base + rank_in_wave;
+        L.srt_key[dst] = key;
+        L.srt_pos[dst] = tid;
     }
-    __syncthreads();                                     // cnt is dead from here: its memory takes the contributions
-    if (pb && tid == 0) pb[3] = wall_clock64();
-    float* lds_t = reinterpret_cast<float*>(dyn);
+    __syncthreads();
+}
 
-    // ---- this slice's entries: forward + contribution
+// grid = (nsort + ntiles * G / EPG, 2).
+//  * blocks [0, nsort), y == 0: look-ahead - tile_sort one (side, tile) of the NEXT batch and publish its
+//    packed table and its sorted records; that work has no dependence on the tables, so it rides
+//    here, in the shadow of this step's reduce, instead of heading the next step's critical path.
+//  * the other blocks: block (tile, slice, side) owns EPG pieces of 1024/G consecutive entries of the
+//    tile's sorted list - read from the records the previous launch published, or, without look-ahead,
+//    after repeating the tile's sort itself (every block of a tile does: cheap next to a launch and
+//    two more dependent memory round trips).  One lane group per entry loads P[u], Q[i] once, forms
+//    the logit and g = dcost/dlogit exactly as K1 does (both sides compute the same g from the same
+//    registers), its contribution goes to LDS, and the runs inside each piece are summed by doubling
+//    (K3).  Piece sums land at the tile-sorted position.  The item side also writes the logits and
+//    the per-block {loss, reg, sum g}.  EPG is chosen so that the grid stays within one block per CU.
+template <int G, int VEC, int EPG>
+__global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
+    constexpr int EPB = 1024 / G;                        // entries per piece = lane groups per block
+    constexpr int EPS = EPB * EPG;                       // entries per block
+    constexpr int NSL = 1024 / EPS;                      // blocks per tile
+    extern __shared__ int32_t dyn[];                     // sort: cnt[nbins]; then the contributions (ping-pong)
+    __shared__ int32_t rec_u[1024], rec_i[1024], srt_key[1024], srt_pos[1024];
+    __shared__ float rec_r[1024];
+    __shared__ float lds_gb[2 * EPS];
+    __shared__ int32_t lds_key[EPS];
+    __shared__ int32_t wtot[16];
+    const int tid = threadIdx.x;
+    const bool ahead = (int)blockIdx.x < nsort;          // look-ahead block: sort (side, tile) of the next batch
+    if (ahead && blockIdx.y) return;
+    const int bx = ahead ? 0 : (int)blockIdx.x - nsort;
+    const int side = ahead ? (int)blockIdx.x / a.next_ntiles : (int)blockIdx.y;      // 0: user rows, 1: item rows
+    const int tile = ahead ? (int)blockIdx.x % a.next_ntiles : bx / NSL;
+    const int slice = bx % NSL;
+    const int64_t tile0 = (int64_t)tile * 1024;
+    const int64_t Bt = ahead ? a.next_B : a.B;
+    const int nvalid = (Bt - tile0 < 1024) ? (int)(Bt - tile0) : 1024;
+    if (!ahead && slice * EPS >= nvalid) {               // a short last tile: nothing in this slice
+        if (side == 1 && tid < 4) a.partials[(size_t)bx * 4 + tid] = 0.f;
+        return;
+    }
+    const bool presorted = a.srt[0] != nullptr;
+    const int nb = a.nbins[side];
+    if (ahead || !presorted) {
+        tile_sort(dyn, rec_u, rec_i, rec_r, srt_key, srt_pos, wtot, ahead ? a.next_ids : a.ids, a.store, a.u, a.it, a.r, tile0,
+                  nvalid, side, nb, a.N, a.U, a.I, a.err);
+        if (ahead) {                                     // publish the packed table and the sorted records
+            for (int b = tid; b < nb; b += 1024) a.next_tab[side][(size_t)tile * nb + b] = dyn[b];
+            if (tid < nvalid) {
+                const int pl = srt_pos[tid];
+                a.next_srt[side][tile0 + tid] = make_int4(rec_u[pl], rec_i[pl], __float_as_int(rec_r[pl]), pl);
+            }
+            return;
+        }
+        // the tile's packed lookup table, written once: its bins are dealt round the tile's active blocks
+        const int nact = (nvalid + EPS - 1) / EPS;
+        for (int b = slice * 1024 + tid; b < nb; b += nact * 1024) a.tab[side][(size_t)tile * nb + b] = dyn[b];
+        __syncthreads();                                 // cnt is dead from here: its memory takes the contributions
+    }
+    float* bufv[2] = {reinterpret_cast<float*>(dyn), reinterpret_cast<float*>(dyn) + EPG * 1024 * VEC};
+    float* bufb[2] = {lds_gb, lds_gb + EPS};
+
+    // ---- this block's entries (EPG per lane group, one from each piece): forward + contribution
     const int grp = tid / G, gl = tid % G, d0 = gl * VEC;
     const int D = a.D;
-    const int jl = slice * EPB + grp;
-    const bool ev = jl < nvalid;
-    int32_t row = -1, prev = -2, pl = 0;
-    if (ev) {
-        row = srt_key[jl];
-        prev = (jl > 0) ? srt_key[jl - 1] : -2;
-        pl = srt_pos[jl];
-    }
-    const bool head = ev && prev != row;                 // jl == 0: the sorted order restarts with the tile
-    const bool pstart = ev && (head || grp == 0);
-    Frag<VEC> t;
+    const float mu = *a.mu;
+    int jl[EPG], bpos[EPG];
+    int32_t row[EPG], uu[EPG], ii[EPG];
+    float rr[EPG];
+    bool ev[EPG], pstart[EPG];
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) t.v[q] = 0.f;
-    float tb = 0.f;
+    for (int h = 0; h < EPG; ++h) {
+        jl[h] = slice * EPS + h * EPB + grp;
+        ev[h] = jl[h] < nvalid;
+        row[h] = -1; uu[h] = 0; ii[h] = 0; rr[h] = 0.f; bpos[h] = 0;
+        int32_t prev = -2;
+        if (ev[h]) {
+            if (presorted) {
+                const int4* sr = a.srt[side] + tile0 + jl[h];
+                const int4 rec = *sr;
+                uu[h] = rec.x; ii[h] = rec.y; rr[h] = __int_as_float(rec.z); bpos[h] = rec.w;
+                row[h] = side == 0 ? rec.x : rec.y;
+                if (jl[h] > 0) prev = reinterpret_cast<const int32_t*>(sr - 1)[side];
+            } else {
+                row[h] = srt_key[jl[h]];
+                if (jl[h] > 0) prev = srt_key[jl[h] - 1];
+                bpos[h] = srt_pos[jl[h]];
+                uu[h] = rec_u[bpos[h]]; ii[h] = rec_i[bpos[h]]; rr[h] = rec_r[bpos[h]];
+            }
+        }
+        pstart[h] = ev[h] && (prev != row[h] || grp == 0);       // run head, or first entry of the piece
+    }
+    Frag<VEC> p[EPG], q[EPG];
+    float bu_[EPG], bi_[EPG];
+#pragma unroll
+    for (int h = 0; h < EPG; ++h) {                      // all row gathers in flight together
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { p[h].v[e] = 0.f; q[h].v[e] = 0.f; }
+        bu_[h] = 0.f; bi_[h] = 0.f;
+        if (ev[h]) {
+            p[h] = load_frag<VEC>(a.P + (size_t)uu[h] * D, d0, D);
+            q[h] = load_frag<VEC>(a.Q + (size_t)ii[h] * D, d0, D);
+            bu_[h] = a.bu[uu[h]];
+            bi_[h] = a.bi[ii[h]];
+        }
+    }
+    Frag<VEC> acc[EPG];
+    float gb[EPG];
     float facc[3] = {0.f, 0.f, 0.f};
-    if (ev) {
-        const int32_t uu = rec_u[pl], ii = rec_i[pl];
-        const float rr = rec_r[pl];
-        const Frag<VEC> p = load_frag<VEC>(a.P + (size_t)uu * D, d0, D);
-        const Frag<VEC> q = load_frag<VEC>(a.Q + (size_t)ii * D, d0, D);
-        const float bu_ = a.bu[uu], bi_ = a.bi[ii];
+#pragma unroll
+    for (int h = 0; h < EPG; ++h) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[h].v[e] = 0.f;
+        gb[h] = 0.f;
         float sdot = 0.f, sq = 0.f;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const float qv = q.v[e];
-            sdot = fmaf(p.v[e], a.item_abs ? fabsf(qv) : qv, sdot);
-            sq = fmaf(p.v[e], p.v[e], fmaf(qv, qv, sq));
+            const float qv = q[h].v[e];
+            sdot = fmaf(p[h].v[e], a.item_abs ? fabsf(qv) : qv, sdot);
+            sq = fmaf(p[h].v[e], p[h].v[e], fmaf(qv, qv, sq));
         }
         sdot = group_sum<G>(sdot);
-        const float logit = ((sdot + *a.mu) + bu_) + bi_;          // ops.py:45-47 order
-        float gk, l;
-        if (a.loss == 0) {                               // ops.py:124
-            gk = logit - rr;
-            l = 0.5f * gk * gk;
-        } else {                                         // ops.py:125-126
-            gk = sigmoidf_(logit) - rr;
-            l = fmaxf(logit, 0.f) - logit * rr + log1pf(__expf(-fabsf(logit)));
-        }
-        if (side == 1) {
-            if (gl == 0) {
-                if (a.logits) a.logits[tile0 + pl] = logit;
-                facc[0] = l;
-                facc[2] = gk;
-                if (a.reg_bias) sq = fmaf(bu_, bu_, fmaf(bi_, bi_, sq));
+        if (ev[h]) {
+            const float logit = ((sdot + mu) + bu_[h]) + bi_[h];   // ops.py:45-47 order
+            float gk, l;
+            if (a.loss == 0) {                           // ops.py:124
+                gk = logit - rr[h];
+                l = 0.5f * gk * gk;
+            } else {                                     // ops.py:125-126
+                gk = sigmoidf_(logit) - rr[h];
+                l = fmaxf(logit, 0.f) - logit * rr[h] + log1pf(__expf(-fabsf(logit)));
             }
-            facc[1] = 0.5f * sq;                         // tf.nn.l2_loss = sum(x^2)/2
-        }
-        const float ob = side == 0 ? bu_ : bi_;
+            if (side == 1) {
+                if (gl == 0) {
+                    if (a.logits) a.logits[tile0 + bpos[h]] = logit;
+                    facc[0] += l;
+                    facc[2] += gk;
+                    if (a.reg_bias) sq = fmaf(bu_[h], bu_[h], fmaf(bi_[h], bi_[h], sq));
+                }
+                facc[1] += 0.5f * sq;                    // tf.nn.l2_loss = sum(x^2)/2
+            }
+            const float ob = side == 0 ? bu_[h] : bi_[h];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float ov = side == 0 ? p.v[e] : q.v[e];
-            float xv = side == 0 ? q.v[e] : p.v[e];
-            if (side == 0) { if (a.item_abs) xv = fabsf(xv); }
-            else if (a.item_abs) xv = xv * ((ov > 0.f) ? 1.f : ((ov < 0.f) ? -1.f : 0.f));
-            t.v[e] = gk * xv + a.lam * ov;
+            for (int e = 0; e < VEC; ++e) {
+                const float ov = side == 0 ? p[h].v[e] : q[h].v[e];
+                float xv = side == 0 ? q[h].v[e] : p[h].v[e];
+                if (side == 0) { if (a.item_abs) xv = fabsf(xv); }
+                else if (a.item_abs) xv = xv * ((ov > 0.f) ? 1.f : ((ov < 0.f) ? -1.f : 0.f));
+                acc[h].v[e] = gk * xv + a.lam * ov;
+            }
+            gb[h] = a.reg_bias ? (gk + a.lam * ob) : gk;
         }
-        tb = a.reg_bias ? (gk + a.lam * ob) : gk;
+        const int e0 = h * EPB + grp;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bufv[0][(e0 * G + gl) * VEC + e] = acc[h].v[e];
+        if (gl == 0) { bufb[0][e0] = gb[h]; lds_key[e0] = row[h]; }
     }
-    // ---- K3 inside the slice: suffix sums within runs by doubling (log2 EPB rounds, ping-pong in
-    //      LDS).  After round d a group holds the sum of its next 2d entries of the same run; the fixed
-    //      tree order keeps results bit-identical run to run however long the runs are.
-    float* bufv[2] = {lds_t, lds_t + 1024 * VEC};
-    float* bufb[2] = {lds_gb, lds_gb + EPB};
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) bufv[0][(grp * G + gl) * VEC + q] = t.v[q];
-    if (gl == 0) { bufb[0][grp] = tb; lds_key[grp] = row; }
-    if (side == 1) block_sum_store<3, 16>(facc, a.partials + (size_t)blockIdx.x * 4);   // has the barrier
+    if (side == 1) block_sum_store<3, 16>(facc, a.partials + (size_t)bx * 4);   // has the barrier
     else __syncthreads();
-    if (pb && tid == 0) pb[4] = wall_clock64();
-    Frag<VEC> acc = t;
-    float gb = tb;
+    // ---- K3 inside each piece: suffix sums within runs by doubling (log2 EPB rounds, ping-pong in
+    //      LDS).  After round d a group holds the sum of its next 2d entries of the same run; the fixed
+    //      tree order keeps results bit-identical run to run however long the runs are.  A group whose
+    //      run ends within reach is final from then on (ids are sorted, so it can never take again): it
+    //      copies its value to the other buffer once and drops out, so only long runs keep moving data.
+    bool live[EPG];
+#pragma unroll
+    for (int h = 0; h < EPG; ++h) live[h] = ev[h];
     int cur = 0;
 #pragma unroll
     for (int d = 1; d < EPB; d <<= 1) {
-        const int e2 = grp + d;
-        const bool take = ev && e2 < EPB && lds_key[e2] == row;
-        if (take) {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc.v[q] += bufv[cur][(e2 * G + gl) * VEC + q];
-            gb += bufb[cur][e2];
+        for (int h = 0; h < EPG; ++h) {
+            if (live[h]) {
+                const int e0 = h * EPB + grp;
+                const bool take = grp + d < EPB && lds_key[e0 + d] == row[h];
+                if (take) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[h].v[e] += bufv[cur][((e0 + d) * G + gl) * VEC + e];
+                    gb[h] += bufb[cur][e0 + d];
+                } else {
+                    live[h] = false;
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) bufv[cur ^ 1][(e0 * G + gl) * VEC + e] = acc[h].v[e];
+                if (gl == 0) bufb[cur ^ 1][e0] = gb[h];
+            }
         }
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) bufv[cur ^ 1][(grp * G + gl) * VEC + q] = acc.v[q];
-        if (gl == 0) bufb[cur ^ 1][grp] = gb;
         __syncthreads();
         cur ^= 1;
     }
-    if (!pstart) return;
-    const int64_t j = tile0 + jl;
-    store_frag<VEC>(a.grad_rows[side] + (size_t)j * D, d0, D, acc);
-    if (gl == 0) a.grad_bias[side][j] = gb;
-    if (pb && tid == 0) pb[5] = wall_clock64();
+#pragma unroll
+    for (int h = 0; h < EPG; ++h) {
+        if (pstart[h]) {
+            const int64_t j = tile0 + jl[h];
+            store_frag<VEC>(a.grad_rows[side] + (size_t)j * D, d0, D, acc[h]);
+            if (gl == 0) a.grad_bias[side][j] = gb[h];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1014,10 +1090,10 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
 //      tables, so the loads are independent) and then either applies the optimiser (TF1 Adam: every
 //      row; lazy Adam / SGD: touched rows) or - data parallel - writes the row into the dense
 //      gradient buffer.  blockIdx.y == 2 runs the step's finalize (K4).
-template <int G, int VEC, bool WRITE>
+template <int G, int VEC, bool WRITE, int NT>
 __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
-    if (blockIdx.y == 2) {
-        if (blockIdx.x == 0) finalize_body(L.f);
+    if (blockIdx.x == gridDim.x - 1) {                   // the extra block column: K4 (optional), nothing else
+        if (blockIdx.y == 0 && L.with_fin) finalize_body(L.f);
         return;
     }
     const TileDenseArgs& a = L.a[blockIdx.y];
@@ -1029,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
     const int D = a.D;
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
     for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / G; row < a.rows;
-         row += (int64_t)gridDim.x * GPB) {
+         row += (int64_t)(gridDim.x - 1) * GPB) {
         const size_t roff = (size_t)row * D;
         Frag<VEC> w, mrow, vrow;
 #pragma unroll
@@ -1053,43 +1129,70 @@ __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
         for (int q = 0; q < VEC; ++q) tot.v[q] = 0.f;
         float gb = 0.f;
         bool touched = false;
+        // one round trip for all NT table entries, then the piece heads in batches of NB whose
+        // addresses are all known up front (NT <= 12: a single batch)
+        constexpr int NB = (NT > 12) ? 8 : NT;
+        int32_t ent[NT];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half * 8 < a.ntiles) {                   // uniform
-                int32_t cn[8], of[8];
+        for (int t = 0; t < NT; ++t) ent[t] = (t < a.ntiles) ? a.tab[(size_t)t * a.nbins + row] : 0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int tt = half * 8 + t;
-                    const int32_t e = (tt < a.ntiles) ? a.tab[(size_t)tt * a.nbins + row] : 0;
-                    cn[t] = e >> 16;                      // entries of tile tt for this row (<= 1024)
-                    of[t] = e & 0xffff;                   // where its run starts in the tile's sorted list
-                }
-                Frag<VEC> x[8];
-                float xb[8];
+        for (int t0 = 0; t0 < NT; t0 += NB) {
+            Frag<VEC> x[NB];
+            float xb[NB];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {            // unconditional loads (safe address when absent)
-                    const int64_t j = cn[t] ? (int64_t)(half * 8 + t) * 1024 + of[t] : 0;
+            for (int t = 0; t < NB; ++t) {               // predicated: a dummy address would be one hot L2 line
+                const int32_t e = ent[t0 + t];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) x[t].v[q] = 0.f;
+                xb[t] = 0.f;
+                if (e >> 16) {
+                    const int64_t j = (int64_t)(t0 + t) * 1024 + (e & 0xffff);
                     x[t] = load_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D);
                     xb[t] = a.grad_bias[j];
                 }
+            }
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    if (cn[t]) {
-                        touched = true;
+            for (int t = 0; t < NB; ++t) {               // head pieces, added in tile order
+                if (ent[t0 + t] >> 16) {
+                    touched = true;
 #pragma unroll
-                        for (int q = 0; q < VEC; ++q) tot.v[q] += x[t].v[q];
-                        gb += xb[t];
-                        const int64_t j = (int64_t)(half * 8 + t) * 1024 + of[t];
-                        const int64_t end = j + cn[t];
-                        for (int64_t p = (j / EPB + 1) * EPB; p < end; p += EPB) {     // further pieces (hot rows)
-                            const Frag<VEC> y = load_frag<VEC>(a.grad_rows + (size_t)p * D, d0, D);
-#pragma unroll
-                            for (int q = 0; q < VEC; ++q) tot.v[q] += y.v[q];
-                            gb += a.grad_bias[p];
-                        }
-                    }
+                    for (int q = 0; q < VEC; ++q) tot.v[q] += x[t].v[q];
+                    gb += xb[t];
                 }
             }
+        }
+        // hot rows: runs cut into several pieces.  Round k adds the k-th continuation piece of every
+        // tile (loads of a round are independent), so the chain is as long as the most-split run of
+        // one tile, not the sum over tiles.  Fixed order: round-major, tile-minor.
+        for (int k = 1;; ++k) {
+            bool more = false;
+#pragma unroll
+            for (int t0 = 0; t0 < NT; t0 += NB) {
+                Frag<VEC> y[NB];
+                float yb[NB];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const int32_t e = ent[t0 + t];
+                    const int64_t j = (int64_t)(t0 + t) * 1024 + (e & 0xffff);
+                    const int64_t pp = (j / EPB + k) * EPB;
+                    const bool has = (e >> 16) && pp < j + (e >> 16);
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) y[t].v[q] = 0.f;
+                    yb[t] = 0.f;
+                    if (has) {
+                        y[t] = load_frag<VEC>(a.grad_rows + (size_t)pp * D, d0, D);
+                        yb[t] = a.grad_bias[pp];
+                        more = true;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) tot.v[q] += y[t].v[q];
+                    gb += yb[t];
+                }
+            }
+            if (!more) break;
         }
         if constexpr (WRITE) {
             if (touched) {
@@ -1124,8 +1227,6 @@ __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
     }
 }
 
-// ------------------------------------------------------------------------------------
-// K4  finalize (body in finalize.inc.h; the small-table path runs it inside the csort scan launch)
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a) { finalize_body(a); }
 
 // ------------------------------------------------------------------------------------
@@ -1209,25 +1310,41 @@ void launch_front(const FrontArgs& fa, int G, int VEC, hipStream_t s) {
 #undef TFR_FRONT_CASE
 }
 
+int tile_step_epg(int ntiles, int G, int VEC) {
+    // smallest EPG in {1, 2, 4} that brings the grid (two sides) down to one block per CU (256 CUs),
+    // as far as the ping-pong buffers (2 * EPG * 1024 * VEC floats) leave room in the 160 KB of LDS
+    int epg = 1;
+    while (epg < 4 && epg < G && ntiles * (G / epg) * 2 > 256 &&
+           (size_t)2 * (2 * epg) * 1024 * VEC * 4 + 40 * 1024 <= 160 * 1024) epg *= 2;
+    return epg;
+}
+
 void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s) {
     const int nbmax = a.nbins[0] > a.nbins[1] ? a.nbins[0] : a.nbins[1];
+    const int epg = tile_step_epg(a.ntiles, G, VEC);
     size_t dyn = (size_t)nbmax * 4;                       // bins during the sort, contributions afterwards
-    if (dyn < (size_t)2 * 1024 * VEC * 4) dyn = (size_t)2 * 1024 * VEC * 4;     // ping-pong buffers of the in-slice reduce
-    const dim3 grid(a.ntiles * G, 2);
-#define TFR_TS_CASE(g, v)                                                                             \
-    if (G == g && VEC == v) {                                                                         \
+    if (dyn < (size_t)2 * epg * 1024 * VEC * 4) dyn = (size_t)2 * epg * 1024 * VEC * 4;   // ping-pong buffers of the reduce
+    const int nsort = a.next_ids ? 2 * a.next_ntiles : 0;         // look-ahead sort blocks come first
+    const dim3 grid(nsort + a.ntiles * (G / epg), 2);
+#define TFR_TS_LAUNCH(g, v, e)                                                                        \
+    {                                                                                                 \
         static bool attr = false;                                                                     \
         if (!attr) {                                                                                  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_step<g, v>),               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, CSORT_MAX_BINS * 4); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_step<g, v, e>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);        \
             attr = true;                                                                              \
         }                                                                                             \
-        hipLaunchKernelGGL((k_tile_step<g, v>), grid, dim3(1024), dyn, s, a);                         \
+        hipLaunchKernelGGL((k_tile_step<g, v, e>), grid, dim3(1024), dyn, s, a, nsort);               \
+    }
+#define TFR_TS_CASE(g, v)                                                                             \
+    if (G == g && VEC == v) {                                                                         \
+        if (epg == 1) TFR_TS_LAUNCH(g, v, 1) else if (epg == 2) TFR_TS_LAUNCH(g, v, 2) else TFR_TS_LAUNCH(g, v, 4) \
         return;                                                                                       \
     }
     TFR_TS_CASE(4, 4) TFR_TS_CASE(8, 4) TFR_TS_CASE(16, 4) TFR_TS_CASE(32, 4) TFR_TS_CASE(64, 4)
     TFR_TS_CASE(4, 1) TFR_TS_CASE(8, 1) TFR_TS_CASE(16, 1) TFR_TS_CASE(32, 1) TFR_TS_CASE(64, 1)
 #undef TFR_TS_CASE
+#undef TFR_TS_LAUNCH
 }
 
 void launch_forward(const FwdArgs& a, int mode, int G, int VEC, int grid, hipStream_t s) {
@@ -1289,15 +1406,25 @@ void launch_dense_tiles(const TileDenseLaunch& L, bool write, bool with_fin, int
     int64_t nb = (rows + gpb - 1) / gpb;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
-    const dim3 grid((int)nb, with_fin ? 3 : 2);
+    const dim3 grid((int)nb + 1, 2);                     // + one block column for K4
+    TileDenseLaunch LL = L;
+    LL.with_fin = with_fin ? 1 : 0;
+#define TFR_DT_LAUNCH(g, v, wr, nt) hipLaunchKernelGGL((k_dense_tiles<g, v, wr, nt>), grid, dim3(256), 0, s, LL)
 #define TFR_DT_CASE(g, v)                                                                         \
     if (G == g && VEC == v) {                                                                     \
-        if (write) hipLaunchKernelGGL((k_dense_tiles<g, v, true>), grid, dim3(256), 0, s, L);     \
-        else hipLaunchKernelGGL((k_dense_tiles<g, v, false>), grid, dim3(256), 0, s, L);          \
+        const int nt = L.a[0].ntiles;                                                             \
+        if (write) {                                                                              \
+            if (nt <= 4) TFR_DT_LAUNCH(g, v, true, 4); else if (nt <= 8) TFR_DT_LAUNCH(g, v, true, 8);      \
+            else if (nt <= 12) TFR_DT_LAUNCH(g, v, true, 12); else TFR_DT_LAUNCH(g, v, true, 16);           \
+        } else {                                                                                  \
+            if (nt <= 4) TFR_DT_LAUNCH(g, v, false, 4); else if (nt <= 8) TFR_DT_LAUNCH(g, v, false, 8);    \
+            else if (nt <= 12) TFR_DT_LAUNCH(g, v, false, 12); else TFR_DT_LAUNCH(g, v, false, 16);         \
+        }                                                                                         \
         return;                                                                                   \
     }
     TFR_DT_CASE(4, 4) TFR_DT_CASE(8, 4) TFR_DT_CASE(16, 4) TFR_DT_CASE(32, 4) TFR_DT_CASE(64, 4)
     TFR_DT_CASE(4, 1) TFR_DT_CASE(8, 1) TFR_DT_CASE(16, 1) TFR_DT_CASE(32, 1) TFR_DT_CASE(64, 1)
+#undef TFR_DT_LAUNCH
 #undef TFR_DT_CASE
 }
 
