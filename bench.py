@@ -84,8 +84,12 @@ def algo_bytes(kernel, B, D, U, I, adam_mode):
             # big tables: forward inside the item side - P,Q,m,v rows in; w,m,v + the per-entry Q copy
             # out; ids, position, key, rating, biases, g / logit out
             return B * (32 * D + 48)
-        # partner row + own row + scratch row out + g, id, pos, key; small tables: both sides in one launch
-        return B * (12 * D + 24) * (2 if small else 1)
+        if small:
+            # k_tile_step: per side the sorted record (16 B), P and Q rows and biases, the piece sum out;
+            # the look-ahead sort of the next batch: id, store record, sorted record out per side, lookup tables
+            return B * (2 * (16 + 8 * D + 8 + 4 * D + 4) + 8 + 16 + 2 * 16) + 2 * ((B + 1023) // 1024) * 4 * (1 << 13)
+        # partner row + own row + scratch row out + g, id, pos, key
+        return B * (12 * D + 24)
     if kernel == "reduce_user":
         if adam_mode == "lazy":             # partner row + own w,m,v read + w,m,v write + bias slots
             return B * (28 * D + 16 + 24)
@@ -420,12 +424,12 @@ def main():
     avg_s = kern[dom]["total_ms"] / kern[dom]["launches"] * 1e-3
     gbs = per_launch / launches_per_step / avg_s / 1e9 if avg_s > 0 else 0.0
     symbols = {"forward": "k_front (forward + fused gather + tile-local counting sort) / k_forward", "sort": "k_csort_* / k_rsort_*",
-               "reduce_item": "k_seg_reduce<scratch> (small tables: item+user sides in one launch)", "reduce_user": "k_seg_reduce<adam|sgd> (fused apply)",
+               "reduce_item": "k_tile_step (small tables: forward + in-tile segmented reduce of both sides + look-ahead sort of the next batch) / k_seg_reduce", "reduce_user": "k_seg_reduce<adam|sgd> (fused apply)",
                "apply": "k_dense_tiles (combine per-tile partials + optimiser + finalize) / k_adam_dense / k_apply_rows", "finalize": "k_finalize",
                "gather": "k_gather_triples"}
     roofline = dict(kernel=dom, kernel_symbol=symbols.get(dom, dom), bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                    traffic=profiled_traffic({"forward": "k_front<16, 4>", "reduce_item": "k_seg_reduce<16, 4, 0>",
-                                              "apply": "k_dense_tiles<16, 4, false>"}.get(dom, "-")) if args.workload == "c2" else None,
+                    traffic=profiled_traffic({"reduce_item": "k_tile_step<16, 4, 2>",
+                                              "apply": "k_dense_tiles<16, 4, false, 12>"}.get(dom, "-")) if args.workload == "c2" else None,
                     traffic_source="profiles/r01_pmc_summary.csv: L2<->fabric requests of this kernel (served by the Infinity Cache at this size)",
                     algorithmic_bytes_per_step=per_launch, avg_launch_us=avg_s * 1e6,
                     note="tables (2.6 MB + Adam state) are L2/Infinity-Cache resident at this size; "
