@@ -768,7 +768,7 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
                 ts.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
                 ts.nbins[0] = 1 << m->bits_u; ts.nbins[1] = 1 << m->bits_i;
                 ts.lam = o.reg;
-                nblk = ts.ntiles * (m->G / tile_step_epg(ts.ntiles, m->G, m->VEC));
+                nblk = ts.ntiles * m->G;            // one {loss, reg, sum g} slot per piece
                 f.nblk = nblk;
                 {
                     Prof p(m, TFR_K_REDUCE_ITEM);

@@ -9,6 +9,7 @@
 //
 // Reference semantics restated per kernel; file:line into the reference tree.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include "svd_kernels.h"
 #include "finalize.inc.h"
@@ -345,6 +346,26 @@ __global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
     }
 }
 
+// per-piece block sums for k_tile_step: val[3 * h + c] -> out[h * 4 + c]; 16 waves; has a barrier
+template <int EPG>
+__device__ __forceinline__ void block_sum_pieces(float (&val)[3 * EPG], float* out) {
+    __shared__ float red[16][3 * EPG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3 * EPG; ++c) {
+        const float s2 = wave_sum(val[c]);
+        if (lane == 0) red[wave][c] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * EPG) {
+        const int c = threadIdx.x;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; w += 4) t += (red[w][c] + red[w + 1][c]) + (red[w + 2][c] + red[w + 3][c]);
+        out[(c / 3) * 4 + (c % 3)] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // K1+K2+K3 for small tables in one launch (k_tile_step).
 //
@@ -430,8 +451,8 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     extern __shared__ int32_t dyn[];                     // sort: cnt[nbins]; then the contributions (ping-pong)
     __shared__ int32_t rec_u[1024], rec_i[1024], srt_key[1024], srt_pos[1024];
     __shared__ float rec_r[1024];
-    __shared__ float lds_gb[2 * EPS];
-    __shared__ int32_t lds_key[EPS];
+    __shared__ float lds_gb[2 * EPG * 16];
+    __shared__ int32_t lds_key[EPG * 16];
     __shared__ int32_t wtot[16];
     const int tid = threadIdx.x;
     const bool ahead = (int)blockIdx.x < nsort;          // look-ahead block: sort (side, tile) of the next batch
@@ -444,7 +465,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     const int64_t Bt = ahead ? a.next_B : a.B;
     const int nvalid = (Bt - tile0 < 1024) ? (int)(Bt - tile0) : 1024;
     if (!ahead && slice * EPS >= nvalid) {               // a short last tile: nothing in this slice
-        if (side == 1 && tid < 4) a.partials[(size_t)bx * 4 + tid] = 0.f;
+        if (side == 1 && tid < 4 * EPG) a.partials[(size_t)bx * EPG * 4 + tid] = 0.f;
         return;
     }
     const bool presorted = a.srt[0] != nullptr;
@@ -465,8 +486,6 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
         for (int b = slice * 1024 + tid; b < nb; b += nact * 1024) a.tab[side][(size_t)tile * nb + b] = dyn[b];
         __syncthreads();                                 // cnt is dead from here: its memory takes the contributions
     }
-    float* bufv[2] = {reinterpret_cast<float*>(dyn), reinterpret_cast<float*>(dyn) + EPG * 1024 * VEC};
-    float* bufb[2] = {lds_gb, lds_gb + EPS};
 
     // ---- this block's entries (EPG per lane group, one from each piece): forward + contribution
     const int grp = tid / G, gl = tid % G, d0 = gl * VEC;
@@ -514,7 +533,9 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     }
     Frag<VEC> acc[EPG];
     float gb[EPG];
-    float facc[3] = {0.f, 0.f, 0.f};
+    float facc[3 * EPG];                                 // per piece {loss, reg, sum g}: results do not depend on EPG
+#pragma unroll
+    for (int h = 0; h < 3 * EPG; ++h) facc[h] = 0.f;
 #pragma unroll
     for (int h = 0; h < EPG; ++h) {
 #pragma unroll
@@ -541,11 +562,11 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
             if (side == 1) {
                 if (gl == 0) {
                     if (a.logits) a.logits[tile0 + bpos[h]] = logit;
-                    facc[0] += l;
-                    facc[2] += gk;
+                    facc[3 * h + 0] = l;
+                    facc[3 * h + 2] = gk;
                     if (a.reg_bias) sq = fmaf(bu_[h], bu_[h], fmaf(bi_[h], bi_[h], sq));
                 }
-                facc[1] += 0.5f * sq;                    // tf.nn.l2_loss = sum(x^2)/2
+                facc[3 * h + 1] = 0.5f * sq;             // tf.nn.l2_loss = sum(x^2)/2
             }
             const float ob = side == 0 ? bu_[h] : bi_[h];
 #pragma unroll
@@ -558,43 +579,83 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
             }
             gb[h] = a.reg_bias ? (gk + a.lam * ob) : gk;
         }
-        const int e0 = h * EPB + grp;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) bufv[0][(e0 * G + gl) * VEC + e] = acc[h].v[e];
-        if (gl == 0) { bufb[0][e0] = gb[h]; lds_key[e0] = row[h]; }
     }
-    if (side == 1) block_sum_store<3, 16>(facc, a.partials + (size_t)bx * 4);   // has the barrier
-    else __syncthreads();
-    // ---- K3 inside each piece: suffix sums within runs by doubling (log2 EPB rounds, ping-pong in
-    //      LDS).  After round d a group holds the sum of its next 2d entries of the same run; the fixed
-    //      tree order keeps results bit-identical run to run however long the runs are.  A group whose
-    //      run ends within reach is final from then on (ids are sorted, so it can never take again): it
-    //      copies its value to the other buffer once and drops out, so only long runs keep moving data.
-    bool live[EPG];
+    // ---- K3 inside each piece, in two levels, every sum in a fixed tree order (bit-identical run to
+    //      run however long the runs are):
+    //      1. a wave holds GPW consecutive entries of the piece: suffix sums within runs by doubling,
+    //         in registers (cross-lane moves, no LDS memory, no barrier);
+    //      2. the 16 waves' leading-run sums: the same doubling over 16 values per piece through LDS
+    //         (a value whose run ends within reach is final and drops out);
+    //      3. an entry whose run reaches the end of its wave adds the next wave's total.
+    constexpr int GPW = 64 / G;
+    const int wv = tid >> 6, gw = grp % GPW;
 #pragma unroll
-    for (int h = 0; h < EPG; ++h) live[h] = ev[h];
+    for (int d = 1; d < GPW; d <<= 1) {
+#pragma unroll
+        for (int h = 0; h < EPG; ++h) {
+            const int32_t krow = __shfl_down(row[h], d * G, 64);
+            float xs[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) xs[e] = __shfl_down(acc[h].v[e], d * G, 64);
+            const float xg = __shfl_down(gb[h], d * G, 64);
+            if (ev[h] && gw + d < GPW && krow == row[h]) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[h].v[e] += xs[e];
+                gb[h] += xg;
+            }
+        }
+    }
+    float* wbuf[2] = {reinterpret_cast<float*>(dyn), reinterpret_cast<float*>(dyn) + EPG * 16 * G * VEC};
+    float* wgb[2] = {lds_gb, lds_gb + EPG * 16};
+    bool reach[EPG], live[EPG];
+    Frag<VEC> tacc[EPG];
+    float tgb[EPG];
+#pragma unroll
+    for (int h = 0; h < EPG; ++h) {
+        reach[h] = ev[h] && __shfl(row[h], (GPW - 1) * G + gl, 64) == row[h];     // run reaches the wave's last entry
+        tacc[h] = acc[h];
+        tgb[h] = gb[h];
+        live[h] = gw == 0;                               // one lane group per wave carries the wave's value
+        if (gw == 0) {
+            const int w0 = h * 16 + wv;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) wbuf[0][(w0 * G + gl) * VEC + e] = tacc[h].v[e];
+            if (gl == 0) { wgb[0][w0] = tgb[h]; lds_key[w0] = row[h]; }
+        }
+    }
+    if (side == 1) block_sum_pieces<EPG>(facc, a.partials + (size_t)bx * EPG * 4);   // has the barrier
+    else __syncthreads();
     int cur = 0;
 #pragma unroll
-    for (int d = 1; d < EPB; d <<= 1) {
+    for (int d = 1; d < 16; d <<= 1) {
 #pragma unroll
         for (int h = 0; h < EPG; ++h) {
             if (live[h]) {
-                const int e0 = h * EPB + grp;
-                const bool take = grp + d < EPB && lds_key[e0 + d] == row[h];
+                const int w0 = h * 16 + wv;
+                const bool take = row[h] >= 0 && wv + d < 16 && lds_key[w0 + d] == row[h];
                 if (take) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[h].v[e] += bufv[cur][((e0 + d) * G + gl) * VEC + e];
-                    gb[h] += bufb[cur][e0 + d];
+                    for (int e = 0; e < VEC; ++e) tacc[h].v[e] += wbuf[cur][((w0 + d) * G + gl) * VEC + e];
+                    tgb[h] += wgb[cur][w0 + d];
                 } else {
                     live[h] = false;
                 }
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) bufv[cur ^ 1][(e0 * G + gl) * VEC + e] = acc[h].v[e];
-                if (gl == 0) bufb[cur ^ 1][e0] = gb[h];
+                for (int e = 0; e < VEC; ++e) wbuf[cur ^ 1][(w0 * G + gl) * VEC + e] = tacc[h].v[e];
+                if (gl == 0) wgb[cur ^ 1][w0] = tgb[h];
             }
         }
         __syncthreads();
         cur ^= 1;
+    }
+#pragma unroll
+    for (int h = 0; h < EPG; ++h) {
+        const int w1 = h * 16 + wv + 1;
+        if (reach[h] && wv + 1 < 16 && lds_key[w1] == row[h]) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[h].v[e] += wbuf[cur][(w1 * G + gl) * VEC + e];
+            gb[h] += wgb[cur][w1];
+        }
     }
 #pragma unroll
     for (int h = 0; h < EPG; ++h) {
@@ -1311,11 +1372,12 @@ void launch_front(const FrontArgs& fa, int G, int VEC, hipStream_t s) {
 }
 
 int tile_step_epg(int ntiles, int G, int VEC) {
-    // smallest EPG in {1, 2, 4} that brings the grid (two sides) down to one block per CU (256 CUs),
-    // as far as the ping-pong buffers (2 * EPG * 1024 * VEC floats) leave room in the 160 KB of LDS
+    // smallest EPG in {1, 2, 4} that brings the grid (two sides) down to one block per CU (256 CUs)
+    static int forced = -1;                              // TFR_EPG=1|2|4: A/B override
+    if (forced < 0) { const char* e = getenv("TFR_EPG"); forced = e ? atoi(e) : 0; }
+    if (forced == 1 || ((forced == 2 || forced == 4) && forced <= G)) return forced;
     int epg = 1;
-    while (epg < 4 && epg < G && ntiles * (G / epg) * 2 > 256 &&
-           (size_t)2 * (2 * epg) * 1024 * VEC * 4 + 40 * 1024 <= 160 * 1024) epg *= 2;
+    while (epg < 4 && epg < G && ntiles * (G / epg) * 2 > 256) epg *= 2;
     return epg;
 }
 
@@ -1323,7 +1385,7 @@ void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s) {
     const int nbmax = a.nbins[0] > a.nbins[1] ? a.nbins[0] : a.nbins[1];
     const int epg = tile_step_epg(a.ntiles, G, VEC);
     size_t dyn = (size_t)nbmax * 4;                       // bins during the sort, contributions afterwards
-    if (dyn < (size_t)2 * epg * 1024 * VEC * 4) dyn = (size_t)2 * epg * 1024 * VEC * 4;   // ping-pong buffers of the reduce
+    if (dyn < (size_t)2 * epg * 16 * G * VEC * 4) dyn = (size_t)2 * epg * 16 * G * VEC * 4;   // wave-level ping-pong buffers of the reduce
     const int nsort = a.next_ids ? 2 * a.next_ntiles : 0;         // look-ahead sort blocks come first
     const dim3 grid(nsort + a.ntiles * (G / epg), 2);
 #define TFR_TS_LAUNCH(g, v, e)                                                                        \
