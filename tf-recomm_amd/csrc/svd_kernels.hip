@@ -346,23 +346,36 @@ __global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
     }
 }
 
-// per-piece block sums for k_tile_step: val[3 * h + c] -> out[h * 4 + c]; 16 waves; has a barrier
-template <int EPG>
-__device__ __forceinline__ void block_sum_pieces(float (&val)[3 * EPG], float* out) {
-    __shared__ float red[16][3 * EPG];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// per-piece {loss, reg, sum g} for k_tile_step without a cross-lane reduction in every wave: lane
+// group leaders park the entry's loss and g, every lane its share of the regulariser, in LDS;
+// after the barrier wave (h, c) alone adds piece h's values of kind c in a fixed order.
+// stage: EPG * (2 * EPB + 1024) floats.  16 waves; has one barrier.
+template <int G, int EPG>
+__device__ __forceinline__ void block_sum_pieces(const float (&val)[3 * EPG], float* stage, float* out) {
+    constexpr int EPB = 1024 / G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = tid / G, gl = tid % G;
+    float* sl = stage;                                   // [EPG][EPB]   loss per entry
+    float* sg = stage + EPG * EPB;                       // [EPG][EPB]   g per entry
+    float* sr = stage + 2 * EPG * EPB;                   // [EPG][1024]  regulariser share per lane
 #pragma unroll
-    for (int c = 0; c < 3 * EPG; ++c) {
-        const float s2 = wave_sum(val[c]);
-        if (lane == 0) red[wave][c] = s2;
+    for (int h = 0; h < EPG; ++h) {
+        if (gl == 0) { sl[h * EPB + grp] = val[3 * h + 0]; sg[h * EPB + grp] = val[3 * h + 2]; }
+        sr[h * 1024 + tid] = val[3 * h + 1];
     }
     __syncthreads();
-    if (threadIdx.x < 3 * EPG) {
-        const int c = threadIdx.x;
-        float t = 0.f;
+    if (wave < 3 * EPG) {
+        const int h = wave / 3, c = wave % 3;
+        float x = 0.f;
+        if (c == 1) {
 #pragma unroll
-        for (int w = 0; w < 16; w += 4) t += (red[w][c] + red[w + 1][c]) + (red[w + 2][c] + red[w + 3][c]);
-        out[(c / 3) * 4 + (c % 3)] = t;
+            for (int k = 0; k < 16; ++k) x += sr[h * 1024 + k * 64 + lane];
+        } else {
+            const float* src = (c == 0 ? sl : sg) + h * EPB;
+            for (int k = lane; k < EPB; k += 64) x += src[k];
+        }
+        x = wave_sum(x);
+        if (lane == 0) out[h * 4 + c] = x;
     }
 }
 
@@ -453,6 +466,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     __shared__ float rec_r[1024];
     __shared__ float lds_gb[2 * EPG * 16];
     __shared__ int32_t lds_key[EPG * 16];
+    __shared__ float lds_stage[EPG * (2 * EPB + 1024)];
     __shared__ int32_t wtot[16];
     const int tid = threadIdx.x;
     const bool ahead = (int)blockIdx.x < nsort;          // look-ahead block: sort (side, tile) of the next batch
@@ -623,7 +637,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
             if (gl == 0) { wgb[0][w0] = tgb[h]; lds_key[w0] = row[h]; }
         }
     }
-    if (side == 1) block_sum_pieces<EPG>(facc, a.partials + (size_t)bx * EPG * 4);   // has the barrier
+    if (side == 1) block_sum_pieces<G, EPG>(facc, lds_stage, a.partials + (size_t)bx * EPG * 4);   // has the barrier
     else __syncthreads();
     int cur = 0;
 #pragma unroll
@@ -667,7 +681,6 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     }
 }
 
-// ------------------------------------------------------------------------------------
 // K0  triple gather from the HBM-resident (user,item,rate) store: what
 //     ShuffleIterator.next does on the host (dataio.py:115-117), ids drawn by the host.
 //     (the training path fuses this into K1; this kernel serves forward_resident)
