@@ -183,6 +183,10 @@ int tfr_shard_finish_step(tfr_model* m, const float* d_scalars4 /* global sums *
 int64_t tfr_dp_flat_size(tfr_model* m);
 int tfr_dp_local_grads(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate,
                        int64_t batch, const int64_t* d_store_ids, float* d_flat);
+/* Optional look-ahead for the call above: the store ids (device, same batch size) the NEXT
+ * tfr_dp_local_grads will be given.  Their tile sort then rides in this step's launch instead of
+ * heading the next step (the host knows the id stream: dataio.py:113-117 draws it).  One-shot. */
+int tfr_dp_hint_next(tfr_model* m, const int64_t* d_next_store_ids);
 int tfr_dp_apply(tfr_model* m, float* d_flat);
 int tfr_staged_ids_devptr(tfr_model* m, void** ptr, int64_t* n);
 

@@ -117,6 +117,49 @@ def test_two_rank_data_parallel_large_table_route():
              nprocs=2, join=True)
 
 
+def _dp_resident_worker(rank, world, port, U, I, D, B, steps):
+    """Replicas fed from the resident store with the look-ahead hint (tfr_dp_hint_next): the tile sort of
+    step s+1 rides in step s's launch.  Must equal one oracle step on the global batch, every step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfrecomm_amd import dataparallel, _lib as L
+        torch.cuda.set_device(0)
+        kw = dict(optimizer="adam", adam_mode="tf1")
+        rs = np.random.RandomState(21)
+        t = rand_tables(rs, U, I, D)
+        N = 5000
+        su, si = dup_heavy_ids(rs, U, N), dup_heavy_ids(rs, I, N)
+        sr = rs.randint(1, 6, N).astype(np.float32)
+        ids = rs.randint(0, N, (steps, world * B))
+        ref = make_oracle(U, I, D, t, **kw)
+        be = dataparallel.HipReplica(U, I, D, 0, **kw)
+        be.model.set_tables(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        be.model.upload_triples(su, si, sr)
+        be.model.stage_ids(np.ascontiguousarray(ids[:, rank * B:(rank + 1) * B]))
+        base, _ = be.model.staged_ids_devptr()
+        dp = dataparallel.DataParallelSvd(be)
+        for s in range(steps):
+            scal = dp.train_step(store_ids_ptr=base + s * B * 8, batch=B,
+                                 next_ids_ptr=base + (s + 1) * B * 8 if s + 1 < steps else None)
+            _, wloss, wreg = ref.train_step(su[ids[s]], si[ids[s]], sr[ids[s]])
+            sc = scal.cpu().numpy()
+            tol = RTOL * (s + 1)
+            assert abs(sc[0] - wloss) <= tol * abs(wloss) and abs(sc[1] - wreg) <= tol * abs(wreg), s
+        be.sync()
+        got = be.model.tables()
+        for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+            assert rel_err(got[tid], ref.tables()[tid]) <= RTOL * steps, "table %d" % tid
+        assert be.model.step == steps and float(be.flat.abs().max()) == 0.0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_resident_lookahead():
+    mp.spawn(_dp_resident_worker, args=(2, _free_port(), 300, 200, 64, 1500, 5), nprocs=2, join=True)
+
+
 def test_data_parallel_rejects_lazy_adam():
     import tfrecomm_amd as T
     with T.SvdModel(10, 10, 8, optimizer="adam", adam_mode="lazy") as m:

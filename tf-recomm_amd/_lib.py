@@ -83,6 +83,7 @@ SIGNATURES = {
     "tfr_shard_finish_step": (C.c_int, [_p, _p]),
     "tfr_dp_flat_size": (C.c_int64, [_p]),
     "tfr_dp_local_grads": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _p]),
+    "tfr_dp_hint_next": (C.c_int, [_p, _p]),
     "tfr_dp_apply": (C.c_int, [_p, _p]),
     "tfr_staged_ids_devptr": (C.c_int, [_p, C.POINTER(_p), _i64p]),
     "tfr_fm_create": (C.c_int, [C.POINTER(_p), C.c_int64, C.c_int32, C.POINTER(TfrOpts)]),

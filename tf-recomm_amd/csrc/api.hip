@@ -72,6 +72,7 @@ struct tfr_model {
     // look-ahead of the small-table step: the next batch's tile sort, published by the previous launch
     int4* srt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [parity][side] sorted records {u, i, r, pos}
     const int64_t* pf_ids = nullptr; int64_t pf_B = 0; int pf_par = 0; bool pf_valid = false;
+    const int64_t* dp_next_ids = nullptr;                        // tfr_dp_hint_next: batch of the next tfr_dp_local_grads
     // resident store
     int4* store = nullptr;            // {user, item, rate bits, -} per rating
     int64_t N = 0;
@@ -704,6 +705,50 @@ static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, 
     return TFR_OK;
 }
 
+// K1+K2+K3 of the small-table step in one launch (k_tile_step).  Look-ahead (multi-step calls on the
+// resident store): was this batch's tile sort published by the previous launch?  Is there a next
+// batch to sort in this one?  The packed tables and the sorted records are double-buffered by step
+// parity (hist_* / offs_* serve as the two tables).  *par_out = which table set k_dense_tiles reads.
+static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
+                            float* d_logits, const int64_t* d_store_ids, const int64_t* next_store_ids,
+                            float* gp_rows, int* par_out, int* nblk_out) {
+    const tfr_opts& o = m->o;
+    TileStepArgs ts;
+    memset(&ts, 0, sizeof(ts));
+    ts.P = m->w[TFR_P]; ts.Q = m->w[TFR_Q]; ts.bu = m->w[TFR_BU]; ts.bi = m->w[TFR_BI]; ts.mu = m->w[TFR_MU];
+    ts.u = du; ts.it = di; ts.r = dr;
+    if (d_store_ids) { ts.ids = d_store_ids; ts.store = m->store; }
+    ts.logits = d_logits; ts.partials = m->partials; ts.err = m->d_err;
+    const bool presorted = m->pf_valid && d_store_ids && m->pf_ids == d_store_ids && m->pf_B == B;
+    const int par = presorted ? m->pf_par : 0;
+    int32_t* tabs[2][2] = {{m->hist_u, m->hist_i}, {m->offs_u, m->offs_i}};
+    ts.tab[0] = tabs[par][0]; ts.tab[1] = tabs[par][1];
+    if (presorted) { ts.srt[0] = m->srt[par][0]; ts.srt[1] = m->srt[par][1]; }
+    m->pf_valid = false;
+    if (next_store_ids && d_store_ids) {
+        ts.store = m->store;
+        ts.next_ids = next_store_ids; ts.next_B = B; ts.next_ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+        ts.next_tab[0] = tabs[par ^ 1][0]; ts.next_tab[1] = tabs[par ^ 1][1];
+        ts.next_srt[0] = m->srt[par ^ 1][0]; ts.next_srt[1] = m->srt[par ^ 1][1];
+        m->pf_valid = true; m->pf_ids = next_store_ids; m->pf_B = B; m->pf_par = par ^ 1;
+    }
+    ts.grad_rows[0] = gp_rows; ts.grad_rows[1] = m->gq;
+    ts.grad_bias[0] = m->gbp; ts.grad_bias[1] = m->gbq;
+    ts.B = B; ts.U = m->U; ts.I = m->I; ts.N = m->N;
+    ts.D = m->D; ts.loss = o.loss; ts.item_abs = o.item_abs; ts.reg_bias = o.reg_bias;
+    ts.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+    ts.nbins[0] = 1 << m->bits_u; ts.nbins[1] = 1 << m->bits_i;
+    ts.lam = o.reg;
+    *par_out = par;
+    *nblk_out = ts.ntiles * m->G;            // one {loss, reg, sum g} slot per piece
+    {
+        Prof p(m, TFR_K_REDUCE_ITEM);
+        launch_tile_step(ts, m->G, m->VEC, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
 // one minibatch on device-resident (u, i, r) - or, with d_store_ids, on rows of the resident
 // store gathered inside the forward kernel; out3 = optional device {loss, reg, sum_g} slot
 static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
@@ -739,42 +784,8 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             int par = 0;
             if (one_launch) {
                 // gather + tile-local sort + forward + per-tile reduce of both sides: one launch
-                TileStepArgs ts;
-                memset(&ts, 0, sizeof(ts));
-                ts.P = m->w[TFR_P]; ts.Q = m->w[TFR_Q]; ts.bu = m->w[TFR_BU]; ts.bi = m->w[TFR_BI]; ts.mu = m->w[TFR_MU];
-                ts.u = du; ts.it = di; ts.r = dr;
-                if (d_store_ids) { ts.ids = d_store_ids; ts.store = m->store; }
-                ts.logits = d_logits; ts.partials = m->partials; ts.err = m->d_err;
-                // look-ahead (multi-step calls on the resident store): was this batch's tile sort published by
-                // the previous launch?  Is there a next batch to sort in this one?  The packed tables and the
-                // sorted records are double-buffered by step parity (hist_* / offs_* serve as the two tables).
-                const bool presorted = m->pf_valid && d_store_ids && m->pf_ids == d_store_ids && m->pf_B == B;
-                par = presorted ? m->pf_par : 0;
-                int32_t* tabs[2][2] = {{m->hist_u, m->hist_i}, {m->offs_u, m->offs_i}};
-                ts.tab[0] = tabs[par][0]; ts.tab[1] = tabs[par][1];
-                if (presorted) { ts.srt[0] = m->srt[par][0]; ts.srt[1] = m->srt[par][1]; }
-                m->pf_valid = false;
-                if (next_store_ids && d_store_ids) {
-                    ts.store = m->store;
-                    ts.next_ids = next_store_ids; ts.next_B = B; ts.next_ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
-                    ts.next_tab[0] = tabs[par ^ 1][0]; ts.next_tab[1] = tabs[par ^ 1][1];
-                    ts.next_srt[0] = m->srt[par ^ 1][0]; ts.next_srt[1] = m->srt[par ^ 1][1];
-                    m->pf_valid = true; m->pf_ids = next_store_ids; m->pf_B = B; m->pf_par = par ^ 1;
-                }
-                ts.grad_rows[0] = gp_rows; ts.grad_rows[1] = m->gq;
-                ts.grad_bias[0] = m->gbp; ts.grad_bias[1] = m->gbq;
-                ts.B = B; ts.U = m->U; ts.I = m->I; ts.N = m->N;
-                ts.D = m->D; ts.loss = o.loss; ts.item_abs = o.item_abs; ts.reg_bias = o.reg_bias;
-                ts.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
-                ts.nbins[0] = 1 << m->bits_u; ts.nbins[1] = 1 << m->bits_i;
-                ts.lam = o.reg;
-                nblk = ts.ntiles * m->G;            // one {loss, reg, sum g} slot per piece
+                if ((rc = tile_step_launch(m, du, di, dr, B, d_logits, d_store_ids, next_store_ids, gp_rows, &par, &nblk))) return rc;
                 f.nblk = nblk;
-                {
-                    Prof p(m, TFR_K_REDUCE_ITEM);
-                    launch_tile_step(ts, m->G, m->VEC, s);
-                }
-                HIPCHK(hipGetLastError());
             }
             RedArgs r;
             memset(&r, 0, sizeof(r));
@@ -1510,6 +1521,12 @@ int64_t tfr_dp_flat_size(tfr_model* m) {
     return m->U * m->D + m->I * m->D + m->U + m->I + 4;
 }
 
+int tfr_dp_hint_next(tfr_model* m, const int64_t* d_next_store_ids) {
+    MODEL_ENTER(m);
+    m->dp_next_ids = d_next_store_ids;
+    return TFR_OK;
+}
+
 int tfr_dp_local_grads(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
                        const int64_t* d_store_ids, float* d_flat) {
     MODEL_ENTER(m);
@@ -1520,6 +1537,8 @@ int tfr_dp_local_grads(tfr_model* m, const int32_t* du, const int32_t* di, const
     if (o.optimizer == TFR_OPT_ADAM && o.adam_mode != TFR_ADAM_TF1)
         return fail(TFR_ERR_STATE, "data-parallel steps need dense semantics: Adam tf1 or SGD");
     int rc;
+    const int64_t* next_ids = d_store_ids ? m->dp_next_ids : nullptr;     // one-shot hint (tfr_dp_hint_next)
+    m->dp_next_ids = nullptr;
     if ((rc = ensure_capacity(m, B > 0 ? B : 1))) return rc;
     float* gP = d_flat;
     float* gQ = gP + m->U * m->D;
@@ -1534,38 +1553,24 @@ int tfr_dp_local_grads(tfr_model* m, const int32_t* du, const int32_t* di, const
     f.partials = m->partials; f.scalars = m->scalars; f.out = tail; f.err = m->d_err;
     f.mu = m->w[TFR_MU];
     if (B > 0 && tiles_eligible(m, B)) {
-        // small tables: tile-local order, per-tile piece sums, then one sweep that writes every touched
-        // row's gradient into the flat buffer and reduces the local scalars (K4 without the mu update)
-        if ((rc = front_and_sort(m, du, di, dr, B, nullptr, d_store_ids, f, nblk, fin_done, true))) return rc;
-        RedArgs r;
-        memset(&r, 0, sizeof(r));
-        r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D; r.tile = CSORT_TILE;
-        r.item_abs = o.item_abs; r.reg_bias = o.reg_bias; r.lam = o.reg;
-        RedPair pr;
-        pr.a[0] = r;
-        pr.a[0].side = 1; pr.a[0].ks = m->ks_i; pr.a[0].ps = m->ps_i; pr.a[0].other = du;
-        pr.a[0].own = m->w[TFR_Q]; pr.a[0].partner = m->w[TFR_P]; pr.a[0].own_bias = m->w[TFR_BI];
-        pr.a[0].grad_rows = m->gq; pr.a[0].grad_bias = m->gbq;
-        pr.a[1] = r;
-        pr.a[1].side = 0; pr.a[1].ks = m->ks_u; pr.a[1].ps = m->ps_u; pr.a[1].other = di;
-        pr.a[1].own = m->w[TFR_P]; pr.a[1].partner = m->w[TFR_Q]; pr.a[1].own_bias = m->w[TFR_BU];
-        pr.a[1].grad_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D; pr.a[1].grad_bias = m->gbp;
-        {
-            Prof p(m, TFR_K_REDUCE_ITEM);
-            launch_seg_reduce(pr, 2, RMODE_SCRATCH, m->G, m->VEC, s);
-        }
-        HIPCHK(hipGetLastError());
+        // small tables: k_tile_step (look-ahead sort of the hinted next batch included), then one sweep that
+        // writes every touched row's gradient into the flat buffer and reduces the local scalars (K4 without
+        // the mu update)
+        float* gp_rows = m->gp ? m->gp : m->gq + (size_t)m->cap * m->D;
+        int par = 0;
+        if ((rc = tile_step_launch(m, du, di, dr, B, nullptr, d_store_ids, next_ids, gp_rows, &par, &nblk))) return rc;
+        f.nblk = nblk;
         TileDenseLaunch L;
         memset(&L, 0, sizeof(L));
         TileDenseArgs d;
         memset(&d, 0, sizeof(d));
         d.err = m->d_err; d.D = m->D; d.ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
         L.a[0] = d;
-        L.a[0].tab = m->hist_i; L.a[0].nbins = 1 << m->bits_i; L.a[0].rows = m->I;
+        L.a[0].tab = par ? m->offs_i : m->hist_i; L.a[0].nbins = 1 << m->bits_i; L.a[0].rows = m->I;
         L.a[0].grad_rows = m->gq; L.a[0].grad_bias = m->gbq; L.a[0].out_rows = gQ; L.a[0].out_bias = gbi;
         L.a[1] = d;
-        L.a[1].tab = m->hist_u; L.a[1].nbins = 1 << m->bits_u; L.a[1].rows = m->U;
-        L.a[1].grad_rows = pr.a[1].grad_rows; L.a[1].grad_bias = m->gbp; L.a[1].out_rows = gP; L.a[1].out_bias = gbu;
+        L.a[1].tab = par ? m->offs_u : m->hist_u; L.a[1].nbins = 1 << m->bits_u; L.a[1].rows = m->U;
+        L.a[1].grad_rows = gp_rows; L.a[1].grad_bias = m->gbp; L.a[1].out_rows = gP; L.a[1].out_bias = gbu;
         L.f = f;
         {
             Prof p(m, TFR_K_APPLY);

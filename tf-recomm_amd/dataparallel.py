@@ -36,10 +36,12 @@ class HipReplica(object):
         cur = torch.cuda.current_stream(self.device)
         return None if cur == self.stream else cur
 
-    def local_grads(self, u=None, i=None, r=None, store_ids_ptr=None, batch=None):
+    def local_grads(self, u=None, i=None, r=None, store_ids_ptr=None, batch=None, next_ids_ptr=None):
         cur = self._foreign()
         if cur is not None:
             self.stream.wait_stream(cur)
+        if store_ids_ptr is not None and next_ids_ptr is not None:
+            self.model.dp_hint_next(next_ids_ptr)
         if store_ids_ptr is not None:
             self.model.dp_local_grads(None, None, None, batch, store_ids_ptr, self.flat.data_ptr())
         else:
@@ -74,10 +76,13 @@ class DataParallelSvd(object):
             dist.all_reduce(flat, group=self.group)
         return flat
 
-    def train_step(self, u=None, i=None, r=None, store_ids_ptr=None, batch=None, want_scalars=True):
+    def train_step(self, u=None, i=None, r=None, store_ids_ptr=None, batch=None, want_scalars=True, next_ids_ptr=None):
         """This rank's slice of the global batch.  Returns a copy of the flat buffer's tail
         {loss, reg, sum_g, 0} (global sums), or None with ``want_scalars=False``."""
-        flat = self.backend.local_grads(u, i, r, store_ids_ptr, batch)
+        if next_ids_ptr is not None:
+            flat = self.backend.local_grads(u, i, r, store_ids_ptr, batch, next_ids_ptr)
+        else:
+            flat = self.backend.local_grads(u, i, r, store_ids_ptr, batch)
         self._all_reduce(flat)
         scal = flat[-4:].clone() if want_scalars else None
         self.backend.apply(flat)
@@ -100,7 +105,8 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val):
     torch.cuda.set_stream(be.stream)                   # the collective queues behind the model's kernels
 
     def step(s):
-        dp.train_step(store_ids_ptr=base + s * B * 8, batch=B, want_scalars=False)
+        dp.train_step(store_ids_ptr=base + s * B * 8, batch=B, want_scalars=False,
+                      next_ids_ptr=base + (s + 1) * B * 8 if s + 1 < W + K else None)
     for s in range(W):
         step(s)
     be.sync()

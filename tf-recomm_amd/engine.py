@@ -210,6 +210,10 @@ class SvdModel:
     def dp_flat_size(self):
         return int(self._lib.tfr_dp_flat_size(self._h))
 
+    def dp_hint_next(self, d_next_store_ids):
+        """Look-ahead: the store ids the next ``dp_local_grads`` call will use (device pointer)."""
+        L.check(self._lib.tfr_dp_hint_next(self._h, d_next_store_ids))
+
     def dp_local_grads(self, d_user, d_item, d_rate, batch, d_store_ids, d_flat):
         L.check(self._lib.tfr_dp_local_grads(self._h, d_user, d_item, d_rate, batch, d_store_ids, d_flat))
 
