@@ -4,6 +4,7 @@
 //   -> user-side segmented reduce (+ fused lazy Adam / SGD)  ->  item apply  ->  finalize
 // or, in TF1 Adam mode, both reduces to scratch followed by the dense sweeps.
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -73,6 +74,13 @@ struct tfr_model {
     int4* srt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [parity][side] sorted records {u, i, r, pos}
     const int64_t* pf_ids = nullptr; int64_t pf_B = 0; int pf_par = 0; bool pf_valid = false;
     const int64_t* dp_next_ids = nullptr;                        // tfr_dp_hint_next: batch of the next tfr_dp_local_grads
+    // big-table look-ahead: the next batch is gathered and sorted on a second stream into the alternate
+    // set of batch buffers while this step's bandwidth-bound kernels run
+    struct SortSet { int32_t *d_u = nullptr, *d_i = nullptr; float* d_r = nullptr;
+                     int32_t *ks_u = nullptr, *ps_u = nullptr, *ks_i = nullptr, *ps_i = nullptr; } alt;
+    int64_t alt_cap = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_first = nullptr;
     // resident store
     int4* store = nullptr;            // {user, item, rate bits, -} per rating
     int64_t N = 0;
@@ -153,6 +161,8 @@ static void free_workspace(tfr_model* m) {
     dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
     dfree(m->blocktot_u); dfree(m->blocktot_i);
     for (int pz = 0; pz < 2; ++pz) for (int sd = 0; sd < 2; ++sd) { dfree(m->srt[pz][sd]); m->srt[pz][sd] = nullptr; }
+    dfree(m->alt.d_u); dfree(m->alt.d_i); dfree(m->alt.d_r); dfree(m->alt.ks_u); dfree(m->alt.ps_u); dfree(m->alt.ks_i); dfree(m->alt.ps_i);
+    m->alt = tfr_model::SortSet(); m->alt_cap = 0;
     m->pf_valid = false;
     m->blocktot_u = m->blocktot_i = nullptr;
     m->lrank_u = m->lrank_i = m->hist_u = m->hist_i = nullptr;
@@ -289,6 +299,9 @@ int tfr_destroy(tfr_model* m) {
     dfree(m->map_u); dfree(m->map_i); dfree(m->dg_p); dfree(m->dg_q); dfree(m->dg_bu); dfree(m->dg_bi); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
     dfree(m->store);
     dfree(m->d_ids); dfree(m->ev_u); dfree(m->ev_i); dfree(m->ev_r);
+    if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); }
+    for (int z = 0; z < 2; ++z) { if (m->ev_sorted[z]) (void)hipEventDestroy(m->ev_sorted[z]); if (m->ev_free[z]) (void)hipEventDestroy(m->ev_free[z]); }
+    if (m->ev_first) (void)hipEventDestroy(m->ev_first);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
     return TFR_OK;
@@ -753,7 +766,7 @@ static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, 
 // store gathered inside the forward kernel; out3 = optional device {loss, reg, sum_g} slot
 static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
                           float* d_logits, float* out3, const int64_t* d_store_ids = nullptr,
-                          const int64_t* next_store_ids = nullptr) {
+                          const int64_t* next_store_ids = nullptr, bool presorted_big = false) {
     const tfr_opts& o = m->o;
     const bool adam = o.optimizer == TFR_OPT_ADAM;
     const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
@@ -775,7 +788,7 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         static int split_tiles = -1;   // TFR_TILE_SPLIT=1: the three-launch form (k_front + k_seg_reduce), kept for A/B
         if (split_tiles < 0) { const char* e = getenv("TFR_TILE_SPLIT"); split_tiles = (e && e[0] == '1') ? 1 : 0; }
         const bool one_launch = tiles && !split_tiles;
-        if (!one_launch)
+        if (!one_launch && !(presorted_big && fwd_fused))     // presorted_big: gathered + sorted ahead, on the second stream
             if ((rc = front_and_sort(m, du, di, dr, B, d_logits, d_store_ids, f, nblk, fin_done, tiles, fwd_fused))) return rc;
         if (tiles) {
             // small tables: per-tile sorted order -> piece sums per tile -> one sweep that combines a
@@ -1194,12 +1207,89 @@ static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t 
     return TFR_OK;
 }
 
+static void swap_sortset(tfr_model* m) {
+    std::swap(m->d_u, m->alt.d_u); std::swap(m->d_i, m->alt.d_i); std::swap(m->d_r, m->alt.d_r);
+    std::swap(m->ks_u, m->alt.ks_u); std::swap(m->ps_u, m->alt.ps_u);
+    std::swap(m->ks_i, m->alt.ks_i); std::swap(m->ps_i, m->alt.ps_i);
+}
+
+static int ensure_lookahead(tfr_model* m) {
+    int rc;
+    if (m->alt_cap < m->cap) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(m->alt.d_u); dfree(m->alt.d_i); dfree(m->alt.d_r); dfree(m->alt.ks_u); dfree(m->alt.ps_u); dfree(m->alt.ks_i); dfree(m->alt.ps_i);
+        m->alt = tfr_model::SortSet(); m->alt_cap = 0;
+        if ((rc = dmalloc(&m->alt.d_u, m->cap)) || (rc = dmalloc(&m->alt.d_i, m->cap)) || (rc = dmalloc(&m->alt.d_r, m->cap)) ||
+            (rc = dmalloc(&m->alt.ks_u, m->cap)) || (rc = dmalloc(&m->alt.ps_u, m->cap)) ||
+            (rc = dmalloc(&m->alt.ks_i, m->cap)) || (rc = dmalloc(&m->alt.ps_i, m->cap))) return rc;
+        m->alt_cap = m->cap;
+    }
+    if (!m->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+        for (int z = 0; z < 2; ++z) {
+            HIPCHK(hipEventCreateWithFlags(&m->ev_sorted[z], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&m->ev_free[z], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&m->ev_first, hipEventDisableTiming));
+    }
+    return TFR_OK;
+}
+
+// Big tables, touched-rows optimiser: gather + radix sort (+ id range check) of batch s+1 do not depend
+// on the tables, are a few small latency-bound launches, and would otherwise head every step; they run
+// on a second stream into the alternate buffer set while step s's HBM-bound kernels own the CUs.
+static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, int32_t nsteps, float* loss_out) {
+    int rc;
+    if ((rc = ensure_lookahead(m))) return rc;
+    hipStream_t main_s = m->stream;
+    FinArgs fdummy;
+    memset(&fdummy, 0, sizeof(fdummy));
+    int nb0 = 0;
+    bool fd0 = false;
+    auto sort_batch = [&](int64_t step) -> int {           // into the buffer set the model currently points at
+        const int32_t* du = m->d_u; const int32_t* di = m->d_i; const float* dr = m->d_r;
+        return front_and_sort(m, du, di, dr, B, nullptr, m->d_ids + (first_step + step) * B, fdummy, nb0, fd0, false, true);
+    };
+    if ((rc = sort_batch(0))) return rc;
+    HIPCHK(hipEventRecord(m->ev_first, main_s));
+    for (int32_t s = 0; s < nsteps; ++s) {
+        const int z = s & 1;
+        if (s + 1 < nsteps) {
+            swap_sortset(m);                               // the other set: target of the look-ahead sort
+            if (s == 0) HIPCHK(hipStreamWaitEvent(m->stream2, m->ev_first, 0));      // sort scratch is shared
+            else HIPCHK(hipStreamWaitEvent(m->stream2, m->ev_free[z ^ 1], 0));       // step s-1 has finished with this set
+            m->stream = m->stream2;
+            rc = sort_batch(s + 1);
+            m->stream = main_s;
+            if (!rc) rc = hipEventRecord(m->ev_sorted[z ^ 1], m->stream2) == hipSuccess ? TFR_OK : fail(TFR_ERR_HIP, "event record");
+            swap_sortset(m);
+            if (rc) return rc;
+        }
+        if (s > 0) HIPCHK(hipStreamWaitEvent(main_s, m->ev_sorted[z], 0));
+        if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr, loss_out ? m->step_out + (size_t)s * 4 : nullptr,
+                                 m->d_ids + (first_step + s) * B, nullptr, true)))
+            return rc;
+        HIPCHK(hipEventRecord(m->ev_free[z], main_s));
+        if (s + 1 < nsteps) swap_sortset(m);               // the next step's batch lives in the other set
+    }
+    HIPCHK(hipStreamSynchronize(m->stream2));              // nothing of ours is left in flight on the side stream
+    return TFR_OK;
+}
+
 static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nsteps, float* loss_out) {
     int rc;
     if ((rc = ensure_capacity(m, B))) return rc;
     if (loss_out && (rc = ensure_step_out(m, nsteps))) return rc;
     const int64_t step0 = m->step;
     const float b1p0 = m->b1p, b2p0 = m->b2p;
+    static int no_ahead = -1;                              // TFR_NO_LOOKAHEAD=1: A/B switch
+    if (no_ahead < 0) { const char* e = getenv("TFR_NO_LOOKAHEAD"); no_ahead = (e && e[0] == '1') ? 1 : 0; }
+    if (nsteps > 1 && fwd_in_reduce(m, B) && !m->prof && !no_ahead) {
+        if ((rc = staged_steps_lookahead(m, first_step, B, nsteps, loss_out))) {
+            (void)hipStreamSynchronize(m->stream2);
+            return rc;
+        }
+    } else {
     for (int32_t s = 0; s < nsteps; ++s) {
         if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr,
                                  loss_out ? m->step_out + (size_t)s * 4 : nullptr,
@@ -1208,6 +1298,7 @@ static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nst
             m->pf_valid = false;
             return rc;
         }
+    }
     }
     if (loss_out) {
         std::vector<float> tmp((size_t)nsteps * 4);
