@@ -154,7 +154,7 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
     m.init_tables(seed=7)
     g = torch.Generator(device="cuda")
     g.manual_seed(13575)
-    nb = 8
+    nb = 8 if B <= 262144 else 2
     du = torch.randint(0, U, (nb, B), dtype=torch.int32, device="cuda", generator=g)
     di = torch.randint(0, I, (nb, B), dtype=torch.int32, device="cuda", generator=g)
     if zipf > 0:        # popularity-skewed items: rank k drawn with probability ~ k^-a (host, seeded), rank -> random row
@@ -452,6 +452,9 @@ def main():
     if not args.no_north_star:
         out["north_star_forward"] = north_star_forward(local_rank)                      # uniform ids: worst case for caches
         out["north_star_forward_zipf"] = north_star_forward(local_rank, zipf=1.05)      # reported separately
+        # the same kernel on eight batches per launch (whole-set inference shape): shows how much of the
+        # per-batch figure is launch ramp and tail, not the kernel (tools/probes/read_bw.hip)
+        out["north_star_forward_8x_batch"] = north_star_forward(local_rank, steps=30, warmup=4, B=8 * 262144)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = time_cpu_baseline(wl, train, ids[W:W + 64])
     out["reference_readme"] = dict(note="README.md:63 batch=10000: 1.1 s/epoch ~ 8.2e5 ratings/s (derived, dim and "
