@@ -201,8 +201,9 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
                 workload="%d users x %d items, dim=%d, batch=%d, %s ids" % (U, I, D, B, "Zipf(%.2f) item" % zipf if zipf > 0 else
                                                                           ("sequential" if sequential else "uniform")),
                 bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                traffic=profiled_traffic("k_forward<32, 4, 0, 4> [%s]" % ("zipf" if zipf > 0 else "uniform"))
-                if (U, I, D, B) == (10_000_000, 1_000_000, 128, 262144) and zipf in (0.0, 1.05) and not sequential else None,
+                traffic=profiled_traffic("k_forward<32, 4, 0, 4> [%s]" % ("8x_batch" if B == 8 * 262144 else "zipf" if zipf > 0 else "uniform"))
+                if (U, I, D) == (10_000_000, 1_000_000, 128) and (B, zipf) in ((262144, 0.0), (262144, 1.05), (8 * 262144, 0.0))
+                and not sequential else None,
                 traffic_source="profiles/r01_pmc_summary.csv (rocprofv3 --pmc, separate passes)",
                 algorithmic_bytes_per_launch=per_launch, avg_launch_us=ms / n * 1e3,
                 ratings_per_s=B * n / (ms * 1e-3), wall_ratings_per_s=B * steps / wall,

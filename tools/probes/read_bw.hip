@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ tab, 
 
 // the forward's full access pattern: two row tables, optionally two 4-byte bias gathers and a 4-byte
 // result per rating (MODE bit 0: biases, bit 1: store)
-template <int UNR, int MODE, bool NT = false>
+template <int UNR, int MODE, int NT = 0>
 __global__ __launch_bounds__(256) void k_pair(const float4* __restrict__ P, const float4* __restrict__ Q,
                                               const float* __restrict__ bu, const float* __restrict__ bi,
                                               const int32_t* __restrict__ iu, const int32_t* __restrict__ ii, size_t n, float* out) {
@@ -64,9 +64,11 @@ __global__ __launch_bounds__(256) void k_pair(const float4* __restrict__ P, cons
             if (NT) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 const v4f va = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&P[(size_t)u[k] * 32 + gl]));
-                const v4f vb = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&Q[(size_t)it[k] * 32 + gl]));
                 a[k] = make_float4(va.x, va.y, va.z, va.w);
-                b[k] = make_float4(vb.x, vb.y, vb.z, vb.w);
+                if (NT == 1) {
+                    const v4f vb = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&Q[(size_t)it[k] * 32 + gl]));
+                    b[k] = make_float4(vb.x, vb.y, vb.z, vb.w);
+                } else b[k] = Q[(size_t)it[k] * 32 + gl];
             } else {
                 a[k] = P[(size_t)u[k] * 32 + gl];
                 b[k] = Q[(size_t)it[k] * 32 + gl];
@@ -148,9 +150,12 @@ int main() {
             float r1 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 1>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
             float r2 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 2>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
             float r3 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 3>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
-            float n1 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 1, true>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
-            float n3 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 3, true>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
-            float n0 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 0, true>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
+            float n1 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 1, 1>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
+            float n3 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 3, 1>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
+            float n0 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 0, 1>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
+            float p3 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 3, 2>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
+            float p0 = time_us([&] { hipLaunchKernelGGL((k_pair<4, 0, 2>), dim3(blocks), dim3(256), 0, 0, x, Q, bu, bi, iu, ii, n, res); });
+            printf("  blocks=%5d  NT for P only: rows only %.1f us | +both %.1f us per 262144\n", blocks, p0 / 8, p3 / 8);
             printf("  blocks=%5d  NT rows: rows only %.1f us | +biases %.1f us | +both %.1f us per 262144\n", blocks, n0 / 8, n1 / 8, n3 / 8);
             {
                 const size_t n1b = 262144;                   // one batch per launch, a different batch each time would be ideal; ids differ per offset

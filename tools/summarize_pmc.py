@@ -4,9 +4,10 @@ profiles/rNN_pmc_summary.csv: per kernel and counter, the per-dispatch mean / mi
 
     python tools/summarize_pmc.py gpurun_out/prof_r01/pmc_* > profiles/r01_pmc_summary.csv
 
-bench.py launches the dim-128 forward (k_forward<32, 4, 0, 4>) in two equal groups - uniform ids,
-then Zipf(1.05) item ids - so that kernel's dispatches are reported as two rows, split at half in
-dispatch order ("[uniform]" / "[zipf]"), next to the combined one."""
+bench.py launches the dim-128 forward (k_forward<32, 4, 0, 4>) in three groups - 110 launches with
+uniform ids, 110 with Zipf(1.05) item ids, 34 on eight batches at once - so that kernel's dispatches
+are also reported per group, in dispatch order ("[uniform]" / "[zipf]" / "[8x_batch]"), next to the
+combined row.  Older runs without the third group (220 dispatches) split in two."""
 import csv
 import glob
 import re
@@ -35,9 +36,12 @@ def main(dirs):
     for (k, c) in sorted(rows):
         seq = [v for _, v in sorted(rows[(k, c)])]
         emit(k, c, seq)
-        if SPLIT in k and len(seq) >= 2 and len(seq) % 2 == 0:
-            emit(k + " [uniform]", c, seq[:len(seq) // 2])
-            emit(k + " [zipf]", c, seq[len(seq) // 2:])
+        if SPLIT in k:
+            groups = {254: (("uniform", 110), ("zipf", 110), ("8x_batch", 34)), 220: (("uniform", 110), ("zipf", 110))}.get(len(seq), ())
+            lo = 0
+            for name, cnt in groups:
+                emit(k + " [%s]" % name, c, seq[lo:lo + cnt])
+                lo += cnt
 
 
 if __name__ == "__main__":
