@@ -891,6 +891,7 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             if (fwd_fused) {           // K1 inside the item side: logits, g, per-block {loss, reg, sum g}
                 ri.partner_bias = m->w[TFR_BU]; ri.mu = m->w[TFR_MU]; ri.r = dr; ri.loss = o.loss;
                 ri.g_out = m->d_g; ri.logits_out = d_logits; ri.partials = m->partials;
+                { static int st = -1; if (st < 0) { const char* e = getenv("TFR_STAGE_SUM"); st = (e && e[0] == '0') ? 0 : 1; } ri.stage_sum = st; }
                 const int epb = 1024 / m->G;
                 nblk = (int)((B + epb - 1) / epb);
             }

@@ -45,6 +45,7 @@ struct RedArgs {
     // are produced here from the rows the reduce loads anyway
     const float* partner_bias; const float* mu; const float* r;
     float* g_out; float* logits_out; float* partials; int32_t loss;
+    int32_t stage_sum;                             // FWD: per-block sums staged through LDS (A/B switch)
     const int32_t* err;
     int64_t B;
     int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;

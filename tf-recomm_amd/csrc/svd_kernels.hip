@@ -109,6 +109,39 @@ __device__ __forceinline__ void block_sum_store(float (&val)[NV], float* out) {
     }
 }
 
+// per-piece {loss, reg, sum g} for k_tile_step without a cross-lane reduction in every wave: lane
+// group leaders park the entry's loss and g, every lane its share of the regulariser, in LDS;
+// after the barrier wave (h, c) alone adds piece h's values of kind c in a fixed order.
+// stage: EPG * (2 * EPB + 1024) floats.  16 waves; has one barrier.
+template <int G, int EPG>
+__device__ __forceinline__ void block_sum_pieces(const float (&val)[3 * EPG], float* stage, float* out) {
+    constexpr int EPB = 1024 / G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = tid / G, gl = tid % G;
+    float* sl = stage;                                   // [EPG][EPB]   loss per entry
+    float* sg = stage + EPG * EPB;                       // [EPG][EPB]   g per entry
+    float* sr = stage + 2 * EPG * EPB;                   // [EPG][1024]  regulariser share per lane
+#pragma unroll
+    for (int h = 0; h < EPG; ++h) {
+        if (gl == 0) { sl[h * EPB + grp] = val[3 * h + 0]; sg[h * EPB + grp] = val[3 * h + 2]; }
+        sr[h * 1024 + tid] = val[3 * h + 1];
+    }
+    __syncthreads();
+    if (wave < 3 * EPG) {
+        const int h = wave / 3, c = wave % 3;
+        float x = 0.f;
+        if (c == 1) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x += sr[h * 1024 + k * 64 + lane];
+        } else {
+            const float* src = (c == 0 ? sl : sg) + h * EPB;
+            for (int k = lane; k < EPB; k += 64) x += src[k];
+        }
+        x = wave_sum(x);
+        if (lane == 0) out[h * 4 + c] = x;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // K1  gather-dot forward (ops.py:13-14,37-38 embedding_lookup x4; ops.py:44-47 dot + biases)
 //     MODE_INFER: logits only                          (svd_train_val.py:120-122)
@@ -343,39 +376,6 @@ __global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
         const int64_t dst = (int64_t)tile * CSORT_TILE + (cnt[key] & 0xffff) + base + rank_in_wave;
         a.ks[col][dst] = fullkey;
         a.ps[col][dst] = (int32_t)k;
-    }
-}
-
-// per-piece {loss, reg, sum g} for k_tile_step without a cross-lane reduction in every wave: lane
-// group leaders park the entry's loss and g, every lane its share of the regulariser, in LDS;
-// after the barrier wave (h, c) alone adds piece h's values of kind c in a fixed order.
-// stage: EPG * (2 * EPB + 1024) floats.  16 waves; has one barrier.
-template <int G, int EPG>
-__device__ __forceinline__ void block_sum_pieces(const float (&val)[3 * EPG], float* stage, float* out) {
-    constexpr int EPB = 1024 / G;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = tid / G, gl = tid % G;
-    float* sl = stage;                                   // [EPG][EPB]   loss per entry
-    float* sg = stage + EPG * EPB;                       // [EPG][EPB]   g per entry
-    float* sr = stage + 2 * EPG * EPB;                   // [EPG][1024]  regulariser share per lane
-#pragma unroll
-    for (int h = 0; h < EPG; ++h) {
-        if (gl == 0) { sl[h * EPB + grp] = val[3 * h + 0]; sg[h * EPB + grp] = val[3 * h + 2]; }
-        sr[h * 1024 + tid] = val[3 * h + 1];
-    }
-    __syncthreads();
-    if (wave < 3 * EPG) {
-        const int h = wave / 3, c = wave % 3;
-        float x = 0.f;
-        if (c == 1) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) x += sr[h * 1024 + k * 64 + lane];
-        } else {
-            const float* src = (c == 0 ? sl : sg) + h * EPB;
-            for (int k = lane; k < EPB; k += 64) x += src[k];
-        }
-        x = wave_sum(x);
-        if (lane == 0) out[h * 4 + c] = x;
     }
 }
 
@@ -762,6 +762,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     __shared__ float lds_t[EPB * G * VEC];
     __shared__ float lds_gb[EPB];
     __shared__ int32_t lds_key[EPB];
+    __shared__ float lds_stage[FWD ? 2 * EPB + 1024 : 1];
     const RedArgs& a = pr.a[blockIdx.y];
     const int32_t err = *a.err;
     const int grp = threadIdx.x / G;
@@ -868,8 +869,10 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) lds_t[(grp * G + gl) * VEC + q] = t.v[q];
     if (gl == 0) { lds_gb[grp] = tb; lds_key[grp] = row; }
-    if constexpr (FWD) block_sum_store<3, 16>(facc, a.partials + (size_t)blockIdx.x * 4);   // has the barrier
-    else __syncthreads();
+    if constexpr (FWD) {                                 // has the barrier
+        if (a.stage_sum) block_sum_pieces<G, 1>(facc, lds_stage, a.partials + (size_t)blockIdx.x * 4);
+        else block_sum_store<3, 16>(facc, a.partials + (size_t)blockIdx.x * 4);
+    } else __syncthreads();
     if (!pstart) return;
 
     Frag<VEC> acc = t;
