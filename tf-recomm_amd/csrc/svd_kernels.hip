@@ -756,7 +756,7 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 //     Both sides run fused: the item side goes first and copies each entry's pre-update Q row
 //     to own_copy_out[pos]; the user side then takes its partner rows from that copy
 //     (partner_by_pos), so neither side sees a row the other has already moved.
-template <int G, int VEC, int RMODE, bool FWD = false>
+template <int G, int VEC, int RMODE, bool FWD = false, bool LEAN = true>
 __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     constexpr int EPB = 1024 / G;
     __shared__ float lds_t[EPB * G * VEC];
@@ -920,7 +920,9 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         }
     } else if constexpr (RMODE == RMODE_ADAM) {
         if (!a.frozen_rows) {
-            Frag<VEC> w = o;
+            // FWD variant: the own row is re-read here (an L2 hit) rather than kept live across the walk -
+            // four registers that decide whether two blocks fit a CU
+            Frag<VEC> w = (FWD && LEAN) ? load_frag<VEC>(a.own_w + roff, d0, D) : o;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], acc.v[q], c);
             store_frag<VEC>(a.own_w + roff, d0, D, w);
@@ -1445,9 +1447,12 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
     int64_t nb = (B + epb - 1) / epb;
     if (nb < 1) nb = 1;
     const dim3 grid((int)nb, n);
+    static int lean = -1;                                // TFR_LEAN=0: A/B switch (own row kept in registers)
+    if (lean < 0) { const char* e = getenv("TFR_LEAN"); lean = (e && e[0] == '0') ? 0 : 1; }
 #define TFR_RED_CASE(g, v)                                                                             \
     if (G == g && VEC == v) {                                                                          \
-        if (fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true>), grid, dim3(1024), 0, s, p); \
+        if (fwd && rmode == RMODE_ADAM && !lean) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, false>), grid, dim3(1024), 0, s, p); \
+        else if (fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true>), grid, dim3(1024), 0, s, p); \
         else if (fwd) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD, true>), grid, dim3(1024), 0, s, p); \
         else if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), grid, dim3(1024), 0, s, p); \
         else if (rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM>), grid, dim3(1024), 0, s, p);  \
