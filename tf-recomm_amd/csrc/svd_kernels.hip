@@ -453,15 +453,16 @@ __device__ __forceinline__ void tile_sort(int32_t* cnt_, int32_t* rec_u_, int32_
 //    after repeating the tile's sort itself (every block of a tile does: cheap next to a launch and
 //    two more dependent memory round trips).  One lane group per entry loads P[u], Q[i] once, forms
 //    the logit and g = dcost/dlogit exactly as K1 does (both sides compute the same g from the same
-//    registers), its contribution goes to LDS, and the runs inside each piece are summed by doubling
-//    (K3).  Piece sums land at the tile-sorted position.  The item side also writes the logits and
-//    the per-block {loss, reg, sum g}.  EPG is chosen so that the grid stays within one block per CU.
+//    registers), and the runs inside each piece are summed in two levels - inside a wave in registers,
+//    across the piece's 16 waves through LDS - always by doubling, i.e. in a fixed tree order (K3).
+//    Piece sums land at the tile-sorted position.  The item side also writes the logits and the
+//    per-piece {loss, reg, sum g}.  EPG is chosen so that the grid stays within one block per CU.
 template <int G, int VEC, int EPG>
 __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     constexpr int EPB = 1024 / G;                        // entries per piece = lane groups per block
     constexpr int EPS = EPB * EPG;                       // entries per block
     constexpr int NSL = 1024 / EPS;                      // blocks per tile
-    extern __shared__ int32_t dyn[];                     // sort: cnt[nbins]; then the contributions (ping-pong)
+    extern __shared__ int32_t dyn[];                     // sort: cnt[nbins]; then the wave-level sums (ping-pong)
     __shared__ int32_t rec_u[1024], rec_i[1024], srt_key[1024], srt_pos[1024];
     __shared__ float rec_r[1024];
     __shared__ float lds_gb[2 * EPG * 16];
