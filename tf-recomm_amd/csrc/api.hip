@@ -70,6 +70,9 @@ struct tfr_model {
     float* step_out = nullptr;        // per-step {loss, reg, sum_g} ring for multi-step calls
     int64_t step_out_cap = 0;
     int32_t* d_err = nullptr;
+    // host-fed calls (tfr_train_step / tfr_forward): one pinned staging buffer each way, so a step is one
+    // H2D copy, the kernels and one D2H copy instead of five pageable transfers
+    int32_t* d_in = nullptr; int32_t* h_in = nullptr; float* h_out = nullptr; int64_t stage_cap = 0;
     // look-ahead of the small-table step: the next batch's tile sort, published by the previous launch
     int4* srt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [parity][side] sorted records {u, i, r, pos}
     const int64_t* pf_ids = nullptr; int64_t pf_B = 0; int pf_par = 0; bool pf_valid = false;
@@ -161,6 +164,10 @@ static void free_workspace(tfr_model* m) {
     dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
     dfree(m->blocktot_u); dfree(m->blocktot_i);
     for (int pz = 0; pz < 2; ++pz) for (int sd = 0; sd < 2; ++sd) { dfree(m->srt[pz][sd]); m->srt[pz][sd] = nullptr; }
+    dfree(m->d_in); m->d_in = nullptr;
+    if (m->h_in) (void)hipHostFree(m->h_in);
+    if (m->h_out) (void)hipHostFree(m->h_out);
+    m->h_in = nullptr; m->h_out = nullptr; m->stage_cap = 0;
     dfree(m->alt.d_u); dfree(m->alt.d_i); dfree(m->alt.d_r); dfree(m->alt.ks_u); dfree(m->alt.ps_u); dfree(m->alt.ks_i); dfree(m->alt.ps_i);
     m->alt = tfr_model::SortSet(); m->alt_cap = 0;
     m->pf_valid = false;
@@ -184,7 +191,7 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     if ((rc = dmalloc(&m->d_u, cap))) return rc;
     if ((rc = dmalloc(&m->d_i, cap))) return rc;
     if ((rc = dmalloc(&m->d_r, cap))) return rc;
-    if ((rc = dmalloc(&m->d_logits, cap))) return rc;
+    if ((rc = dmalloc(&m->d_logits, cap + 4))) return rc;          // + {loss, reg, sum g, error flag} behind the logits
     if ((rc = dmalloc(&m->d_g, cap))) return rc;
     if ((rc = dmalloc(&m->ks_u, cap))) return rc;
     if ((rc = dmalloc(&m->ps_u, cap))) return rc;
@@ -766,7 +773,7 @@ static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, 
 // store gathered inside the forward kernel; out3 = optional device {loss, reg, sum_g} slot
 static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
                           float* d_logits, float* out3, const int64_t* d_store_ids = nullptr,
-                          const int64_t* next_store_ids = nullptr, bool presorted_big = false) {
+                          const int64_t* next_store_ids = nullptr, bool presorted_big = false, bool out_err = false) {
     const tfr_opts& o = m->o;
     const bool adam = o.optimizer == TFR_OPT_ADAM;
     const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
@@ -777,7 +784,7 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     bool fin_done = false, tiles = false;
     FinArgs f;
     memset(&f, 0, sizeof(f));
-    f.partials = m->partials; f.scalars = m->scalars; f.out = out3;
+    f.partials = m->partials; f.scalars = m->scalars; f.out = out3; f.out_err = out_err ? 1 : 0;
     f.mu = m->w[TFR_MU]; f.mu_m = m->m[TFR_MU]; f.mu_v = m->v[TFR_MU]; f.err = m->d_err;
     f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
     f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
@@ -977,6 +984,32 @@ static void rollback_step(tfr_model* m, int64_t step0, float b1p0, float b2p0) {
     m->b2p = b2p0;
 }
 
+// pinned staging for host-fed batches up to 1M ratings (larger ones take the plain copies)
+static const int64_t STAGE_MAX = 1 << 20;
+static int ensure_staging(tfr_model* m, int64_t B) {
+    if (B <= m->stage_cap) return TFR_OK;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    dfree(m->d_in); m->d_in = nullptr;
+    if (m->h_in) (void)hipHostFree(m->h_in);
+    if (m->h_out) (void)hipHostFree(m->h_out);
+    m->h_in = nullptr; m->h_out = nullptr; m->stage_cap = 0;
+    int64_t cap = 1024;
+    while (cap < B) cap *= 2;
+    int rc;
+    if ((rc = dmalloc(&m->d_in, (size_t)3 * cap))) return rc;
+    HIPCHK(hipHostMalloc((void**)&m->h_in, (size_t)3 * cap * 4, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&m->h_out, (size_t)(cap + 4) * 4, hipHostMallocDefault));
+    m->stage_cap = cap;
+    return TFR_OK;
+}
+
+static int report_device_error(tfr_model* m, int32_t e) {
+    HIPCHK(hipMemsetAsync(m->d_err, 0, sizeof(int32_t), m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (e & 1) return fail(TFR_ERR_OOB, "user/item id out of range [0,%lld) / [0,%lld)", (long long)m->U, (long long)m->I);
+    return fail(TFR_ERR_OOB, "store index out of range [0,%lld)", (long long)m->N);
+}
+
 static int check_batch(const void* u, const void* i, int64_t B) {
     if (B < 0) return fail(TFR_ERR_ARG, "negative batch");
     if (B > 0 && (!u || !i)) return fail(TFR_ERR_ARG, "null id pointer");
@@ -1003,6 +1036,17 @@ int tfr_forward(tfr_model* m, const int32_t* u, const int32_t* i, int64_t B, flo
     if (B == 0) return TFR_OK;
     if (!logits_out) return fail(TFR_ERR_ARG, "null logits pointer");
     if ((rc = ensure_capacity(m, B))) return rc;
+    if (B <= STAGE_MAX) {                                // pinned staging: one copy in, one out (+ the error flag)
+        if ((rc = ensure_staging(m, B))) return rc;
+        memcpy(m->h_in, u, (size_t)B * 4);
+        memcpy(m->h_in + B, i, (size_t)B * 4);
+        HIPCHK(hipMemcpyAsync(m->d_in, m->h_in, (size_t)2 * B * 4, hipMemcpyHostToDevice, m->stream));
+        if ((rc = run_forward(m, MODE_INFER, m->d_in, m->d_in + B, nullptr, B, m->d_logits, nullptr, nullptr))) return rc;
+        HIPCHK(hipMemcpyAsync(m->h_out, m->d_logits, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+        if ((rc = check_device_error(m))) return rc;
+        memcpy(logits_out, m->h_out, (size_t)B * 4);
+        return TFR_OK;
+    }
     HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
     if ((rc = run_forward(m, MODE_INFER, m->d_u, m->d_i, nullptr, B, m->d_logits, nullptr, nullptr))) return rc;
@@ -1088,22 +1132,44 @@ int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float
     if (rc) return rc;
     if (B > 0 && !r) return fail(TFR_ERR_ARG, "null rate pointer");
     if ((rc = ensure_capacity(m, B > 0 ? B : 1))) return rc;
-    if (B > 0) {
-        HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
-        HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
-        HIPCHK(hipMemcpyAsync(m->d_r, r, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
-    }
     const int64_t step0 = m->step;
     const float b1p0 = m->b1p, b2p0 = m->b2p;
-    if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, logits_out ? m->d_logits : nullptr, nullptr))) return rc;
     float sc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (logits_out && B > 0)
-        HIPCHK(hipMemcpyAsync(logits_out, m->d_logits, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(sc, m->scalars, 16, hipMemcpyDeviceToHost, m->stream));
-    // synchronous entry point: always validate so a bad batch never advances the step
-    if ((rc = check_device_error(m))) {
-        rollback_step(m, step0, b1p0, b2p0);
-        return rc;
+    if (B > 0 && B <= STAGE_MAX) {
+        // one pinned H2D copy in, the kernels, one D2H copy out: [logits | loss, reg, sum g, error flag]
+        if ((rc = ensure_staging(m, B))) return rc;
+        memcpy(m->h_in, u, (size_t)B * 4);
+        memcpy(m->h_in + B, i, (size_t)B * 4);
+        memcpy(m->h_in + 2 * B, r, (size_t)B * 4);
+        HIPCHK(hipMemcpyAsync(m->d_in, m->h_in, (size_t)3 * B * 4, hipMemcpyHostToDevice, m->stream));
+        const int64_t nl = logits_out ? B : 0;
+        float* out4 = m->d_logits + nl;
+        if ((rc = run_train_step(m, m->d_in, m->d_in + B, reinterpret_cast<const float*>(m->d_in + 2 * B), B,
+                                 logits_out ? m->d_logits : nullptr, out4, nullptr, nullptr, false, true))) return rc;
+        HIPCHK(hipMemcpyAsync(m->h_out, m->d_logits, (size_t)(nl + 4) * 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        const int32_t e = (int32_t)m->h_out[nl + 3];
+        if (e) {                                         // a bad batch never advances the step
+            rollback_step(m, step0, b1p0, b2p0);
+            return report_device_error(m, e);
+        }
+        if (logits_out) memcpy(logits_out, m->h_out, (size_t)B * 4);
+        sc[0] = m->h_out[nl]; sc[1] = m->h_out[nl + 1];
+    } else {
+        if (B > 0) {
+            HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipMemcpyAsync(m->d_r, r, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+        }
+        if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, logits_out ? m->d_logits : nullptr, nullptr))) return rc;
+        if (logits_out && B > 0)
+            HIPCHK(hipMemcpyAsync(logits_out, m->d_logits, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(sc, m->scalars, 16, hipMemcpyDeviceToHost, m->stream));
+        // synchronous entry point: always validate so a bad batch never advances the step
+        if ((rc = check_device_error(m))) {
+            rollback_step(m, step0, b1p0, b2p0);
+            return rc;
+        }
     }
     if (loss_out) *loss_out = sc[0];
     if (reg_out) *reg_out = sc[1];

@@ -43,7 +43,10 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
         a.scalars[0] = tot[0];
         a.scalars[1] = tot[1];
         a.scalars[2] = tot[2];
-        if (a.out) { a.out[0] = tot[0]; a.out[1] = tot[1]; a.out[2] = tot[2]; }
+        if (a.out) {
+            a.out[0] = tot[0]; a.out[1] = tot[1]; a.out[2] = tot[2];
+            if (a.out_err) a.out[3] = (float)*a.err;
+        }
         if (a.update_mu && *a.err == 0) {
             const float g = tot[2];
             float w = *a.mu;

@@ -85,6 +85,7 @@ struct FinArgs {
     float* scalars; float* out;
     float* mu; float* mu_m; float* mu_v; const int32_t* err;
     int32_t update_mu, opt, clear_partials;        // clear_partials: zero partials[0..3] after use
+    int32_t out_err;                               // out[3] = the step's error flag (as a float)
     float alpha, b1, b2, eps, lr;
 };
 
