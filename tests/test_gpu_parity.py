@@ -307,6 +307,41 @@ def test_frozen_tables_var_list():
 
 
 # ------------------------------------------------------------------ resident store / eval
+@pytest.mark.parametrize("case", range(10))
+def test_lookahead_pipelines_equal_single_steps(case):
+    """Multi-step calls sort the NEXT batch ahead of time (small tables: spare blocks of the current
+    launch; big tables: a second stream).  Whatever the shapes, the optimiser and the way the steps are
+    cut into calls, losses and tables must equal host-fed single steps bit for bit."""
+    rs = np.random.RandomState(1000 + case)
+    big = case % 5 == 4                                   # rows beyond the LDS-bin limit: radix sort + stream look-ahead
+    U = int(rs.randint(17000, 30000)) if big else int(rs.choice([40, 700, 6040, 16384]))
+    I = int(rs.randint(200, 20000)) if big else int(rs.choice([30, 500, 3952, 9000]))
+    D = int(rs.choice([8, 20, 64, 128]))
+    B = int(rs.choice([1, 63, 1000, 1024, 1025, 4097, 10000]))
+    N = 50000
+    K = 7
+    opt, mode = [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")][case % 3]
+    if big and mode == "tf1" and opt == "adam":
+        mode = "lazy"
+    kw = dict(optimizer=opt, adam_mode=mode, loss=["mse", "nll"][case % 2], item_abs=bool(case & 2), reg_bias=bool(case & 4))
+    t = rand_tables(rs, U, I, D)
+    su, si = dup_heavy_ids(rs, U, N), dup_heavy_ids(rs, I, N)
+    sr = (rs.rand(N) < 0.5).astype(np.float32) if kw["loss"] == "nll" else rs.randint(1, 6, N).astype(np.float32)
+    ids = rs.randint(0, N, (K, B))
+    with model_from(U, I, D, t, **kw) as a, model_from(U, I, D, t, **kw) as b:
+        a.upload_triples(su, si, sr)
+        a.stage_ids(ids)
+        la = []
+        for first, n in ((0, 1), (1, 2), (3, 4)):         # 1 step (no look-ahead), 2 steps, 4 steps
+            la.extend(a.train_steps_staged(first, B, n, want_loss=True))
+        lb = [b.train_step(su[ids[k]], si[ids[k]], sr[ids[k]])[1] for k in range(K)]
+        assert np.array_equal(np.array(la, np.float32), np.array(lb, np.float32)), (U, I, D, B, kw)
+        ta, tb = a.tables(), b.tables()
+        for tid in TIDS:
+            assert np.array_equal(ta[tid], tb[tid]), (tid, U, I, D, B, kw)
+        assert a.step == b.step == K
+
+
 def test_resident_store_equals_host_fed_steps():
     U, I, D, N, B, K = 300, 200, 64, 5000, 256, 6
     rs = np.random.RandomState(21)

@@ -1409,11 +1409,11 @@ void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s) {
     const dim3 grid(nsort + a.ntiles * (G / epg), 2);
 #define TFR_TS_LAUNCH(g, v, e)                                                                        \
     {                                                                                                 \
-        static bool attr = false;                                                                     \
-        if (!attr) {                                                                                  \
+        static size_t attr = 0;              /* static + dynamic LDS must stay within 160 KB: ask for what is needed */ \
+        if (dyn > attr) {                                                                             \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_step<g, v, e>),            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);        \
-            attr = true;                                                                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);          \
+            attr = dyn;                                                                               \
         }                                                                                             \
         hipLaunchKernelGGL((k_tile_step<g, v, e>), grid, dim3(1024), dyn, s, a, nsort);               \
     }
