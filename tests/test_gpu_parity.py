@@ -307,7 +307,7 @@ def test_frozen_tables_var_list():
 
 
 # ------------------------------------------------------------------ resident store / eval
-@pytest.mark.parametrize("case", range(10))
+@pytest.mark.parametrize("case", range(13))
 def test_lookahead_pipelines_equal_single_steps(case):
     """Multi-step calls sort the NEXT batch ahead of time (small tables: spare blocks of the current
     launch; big tables: a second stream).  Whatever the shapes, the optimiser and the way the steps are
@@ -318,6 +318,8 @@ def test_lookahead_pipelines_equal_single_steps(case):
     I = int(rs.randint(200, 20000)) if big else int(rs.choice([30, 500, 3952, 9000]))
     D = int(rs.choice([8, 20, 64, 128]))
     B = int(rs.choice([1, 63, 1000, 1024, 1025, 4097, 10000]))
+    if case >= 10:                                        # 13..16 tiles: the widest sweep variant; 17: past the tile path
+        U, I, D, B = 6040, 3952, [64, 128, 32][case - 10], [16384, 12289, 16385][case - 10]
     N = 50000
     K = 7
     opt, mode = [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")][case % 3]
