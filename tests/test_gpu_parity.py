@@ -435,6 +435,11 @@ def _sweep_cases():
     cases.append((100, 6040, 3952, 64, 300000, "adam", "tf1", "mse", False, False))
     cases.append((101, 20000, 17000, 32, 5000, "adam", "lazy", "mse", False, False))     # > 16384 rows: radix
     cases.append((102, 3, 2, 64, 9000, "adam", "lazy", "nll", True, True))               # very long runs
+    # small-table step at its widest: four pieces per block (dim 128), 16 tiles, a full 16384-row table
+    cases.append((103, 6040, 3952, 128, 10000, "adam", "tf1", "mse", False, False))
+    cases.append((104, 16384, 500, 128, 10000, "adam", "lazy", "nll", True, True))
+    cases.append((105, 6040, 3952, 64, 16384, "adam", "tf1", "mse", False, True))
+    cases.append((106, 9000, 16384, 256, 12289, "sgd", "tf1", "nll", True, False))
     return cases
 
 

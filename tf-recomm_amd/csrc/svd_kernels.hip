@@ -1391,12 +1391,15 @@ void launch_front(const FrontArgs& fa, int G, int VEC, hipStream_t s) {
 }
 
 int tile_step_epg(int ntiles, int G, int VEC) {
-    // smallest EPG in {1, 2, 4} that brings the grid (two sides) down to one block per CU (256 CUs)
+    // smallest EPG in {1, 2, 4} that brings the grid (two sides) down to one block per CU (256 CUs), as far
+    // as LDS allows: the wave-level ping-pong buffers (2 * EPG * 16 * G * VEC floats) share the 64 KB dynamic
+    // region with the sort's bins; static arrays take another ~40 KB of the CU's 160 KB
+    auto fits = [&](int e) { return (size_t)2 * e * 16 * G * VEC * 4 <= (size_t)64 * 1024; };
     static int forced = -1;                              // TFR_EPG=1|2|4: A/B override
     if (forced < 0) { const char* e = getenv("TFR_EPG"); forced = e ? atoi(e) : 0; }
-    if (forced == 1 || ((forced == 2 || forced == 4) && forced <= G)) return forced;
+    if (forced == 1 || ((forced == 2 || forced == 4) && forced <= G && fits(forced))) return forced;
     int epg = 1;
-    while (epg < 4 && epg < G && ntiles * (G / epg) * 2 > 256) epg *= 2;
+    while (epg < 4 && epg < G && ntiles * (G / epg) * 2 > 256 && fits(2 * epg)) epg *= 2;
     return epg;
 }
 
@@ -1411,8 +1414,9 @@ void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s) {
     {                                                                                                 \
         static size_t attr = 0;              /* static + dynamic LDS must stay within 160 KB: ask for what is needed */ \
         if (dyn > attr) {                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_step<g, v, e>),            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);          \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_step<g, v, e>),              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) \
+                return;                      /* leaves the error for the caller's hipGetLastError() */ \
             attr = dyn;                                                                               \
         }                                                                                             \
         hipLaunchKernelGGL((k_tile_step<g, v, e>), grid, dim3(1024), dyn, s, a, nsort);               \
