@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""One-off fuzz (GPU box): random small-table shapes, one or two training steps each, the HIP path
+"""One-off fuzz (GPU box): random small-table (or, with a third argument "big", large-table) shapes, one or two training steps each, the HIP path
 (single-step and multi-step look-ahead) against the NumPy oracle.  Not part of the test suite - a
 wider net than tests/test_gpu_parity.py::test_random_shapes_two_steps, run by hand:
-    python tools/fuzz_small_tables.py [n_cases] [seed]"""
+    python tools/fuzz_small_tables.py [n_cases] [seed] [big]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,7 @@ from tests.util import RTOL, dup_heavy_ids, make_oracle, rand_tables, rel_err
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+big = len(sys.argv) > 3 and sys.argv[3] == "big"       # rows beyond the LDS-bin limit: radix sort, stream look-ahead
 rs = np.random.RandomState(seed)
 dims = [1, 3, 4, 8, 12, 16, 20, 32, 48, 64, 96, 100, 128, 192, 252, 256]
 bad = 0
@@ -21,6 +22,10 @@ for n in range(n_cases):
     I = int(rs.choice([1, 7, 200, 4096, 3952, 16384, int(rs.randint(1, 16385))]))
     B = int(rs.choice([1, 2, 63, 64, 65, 1023, 1024, 1025, 2048, 5000, 10000, 12288, 12289, 16384, int(rs.randint(1, 16385))]))
     opt, mode = [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")][rs.randint(3)]
+    if big:
+        U = int(rs.choice([16385, 20000, 70000, 200000]))
+        I = int(rs.choice([1, 300, 16384, 16385, 50000]))
+        B = int(rs.choice([1, 31, 1000, 1024, 4097, 20000, 50000]))
     kw = dict(loss=["mse", "nll"][rs.randint(2)], item_abs=bool(rs.randint(2)), reg_bias=bool(rs.randint(2)),
               optimizer=opt, adam_mode=mode, lr=3e-3, reg=0.02)
     t = rand_tables(rs, U, I, D, scale=0.3 / np.sqrt(max(D, 16) / 16))
