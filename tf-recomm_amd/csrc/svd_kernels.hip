@@ -809,7 +809,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     } else if (valid) {
         float gk = 0.f;
         if constexpr (!FWD) gk = a.g[pos];
-        const int32_t pid = a.other[pos];
+        const int32_t pid = a.partner_by_pos ? 0 : a.other[pos];     // not needed when the partner row comes by position
         const float lam_e = a.lam_arr ? a.lam_arr[pos] : a.lam;      // FM: lam - g x^2 per non-zero
         const Frag<VEC> x = a.partner_by_pos ? load_frag<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D)
                                              : load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
