@@ -424,7 +424,7 @@ def main():
     launches_per_step = kern[dom]["launches"] / kp
     avg_s = kern[dom]["total_ms"] / kern[dom]["launches"] * 1e-3
     gbs = per_launch / launches_per_step / avg_s / 1e9 if avg_s > 0 else 0.0
-    symbols = {"forward": "k_front (forward + fused gather + tile-local counting sort) / k_forward", "sort": "k_csort_* / k_rsort_*",
+    symbols = {"forward": "k_forward / k_front (forward + counting-sort rank pass; batches past the tile path)", "sort": "k_csort_* / k_rsort_*",
                "reduce_item": "k_tile_step (small tables: forward + in-tile segmented reduce of both sides + look-ahead sort of the next batch) / k_seg_reduce", "reduce_user": "k_seg_reduce<adam|sgd> (fused apply)",
                "apply": "k_dense_tiles (combine per-tile partials + optimiser + finalize) / k_adam_dense / k_apply_rows", "finalize": "k_finalize",
                "gather": "k_gather_triples"}
