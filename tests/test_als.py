@@ -85,3 +85,32 @@ def test_gpu_als_larger_vs_oracle_and_deterministic():
     assert np.array_equal(outs[0]["U"], outs[1]["U"]) and np.array_equal(outs[0]["W_work"], outs[1]["W_work"])
     assert np.abs(outs[0]["U"] - o.U).max() < 1e-9 and np.abs(outs[0]["V"] - o.V).max() < 1e-9
     assert np.abs(outs[0]["W_user"] - o.W_user).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_gpu_als_long_lists_are_chunked_and_match_oracle():
+    """One work holds a third of all ratings and one user a tenth: their lists are far longer than the
+    chunk size, so their normal equations come from several blocks' partial sums."""
+    import tfrecomm_amd as T
+    rs = np.random.RandomState(5)
+    U, W, n, d = 400, 300, 40000, 12
+    u = rs.randint(0, U, n); w = rs.randint(0, W, n)
+    w[rs.rand(n) < 0.33] = 7                      # ~13000 ratings of one work
+    u[rs.rand(n) < 0.10] = 3                      # ~4000 ratings of one user
+    X = np.stack([u, w], 1)
+    y = rs.randint(1, 6, n).astype(np.float64)
+    Xt = np.stack([rs.randint(0, U, 500), rs.randint(0, W, 500)], 1)
+    yt = rs.randint(1, 6, 500).astype(np.float64)
+    o = AlsOracle(U, W, d, 2, 0.1)
+    np.random.seed(21)
+    o.init_vars()
+    o.load(X, y)
+    o.sweep(); o.sweep()
+    als = T.MangakiALS3(nb_components=d, nb_iterations=2, lambda_=0.1, verbose=False)
+    als.nb_users, als.nb_works = U, W
+    np.random.seed(21)
+    als.fit(X, y, yt, Xt)
+    st = als.state()
+    als.close()
+    for k, want in (("U", o.U), ("V", o.V), ("W_user", o.W_user), ("W_work", o.W_work)):
+        assert np.abs(st[k] - want).max() < 1e-9, k

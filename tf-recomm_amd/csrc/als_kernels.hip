@@ -5,12 +5,15 @@
 //   Inside one half-sweep every entity only reads the OTHER side's tables, so all users (then all
 //   works) are independent: one 256-thread block per entity builds the d x d normal equations from
 //   32-row tiles staged in LDS, factors them (Cholesky; A is SPD because of the lambda*N*I term) and
-//   back-substitutes.  Fixed summation order -> deterministic.  d <= 32.
+//   back-substitutes.  Lists longer than 2048 ratings are cut into chunks: k_als_partial builds each chunk's
+//   partial sums in its own block, the entity's block adds them in list order.  Fixed summation order ->
+//   deterministic.  d <= 32.
 //   predict (als3.py:110-113) at explicit (user, work) pairs - the dense U V^T is never formed.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <new>
 #include <vector>
 #include <algorithm>
@@ -27,7 +30,63 @@ struct AlsFitArgs {
     double* own; double* w_own; const double* other; const double* w_other;
     double bias, lambda;
     int32_t d;
+    // long rating lists are cut into chunks whose partial normal equations are built by other blocks first
+    // (k_als_partial): cfirst[entity] = its first chunk or -1, ccount[entity] chunks, in list order
+    const int32_t* cfirst; const int32_t* ccount;
+    const int32_t* chunk_ent; const int64_t* chunk_lo; const int64_t* chunk_hi; int64_t n_chunks;
+    double* partial;                                   // [n_chunks][d*d + d]
 };
+
+// normal-equation sums over the ratings [lo, hi) of one entity: acc[q] += sum_k rows[k][r] rows[k][c] for the
+// A entries t = tid + 256 q, accb += sum_k coef[k] rows[k][tid]; 32-row tiles staged in LDS; 256 threads
+__device__ __forceinline__ void als_accumulate(const AlsFitArgs& a, int64_t lo, int64_t hi, double b0, double (&acc)[4], double& accb,
+                                               double (*rows)[ALS_MAXD + 1], double* coef) {
+    const int tid = threadIdx.x, d = a.d;
+    for (int64_t s = lo; s < hi; s += ALS_TILE) {
+        const int nk = (int)((hi - s < ALS_TILE) ? hi - s : ALS_TILE);
+        for (int t = tid; t < nk * d; t += 256) {
+            const int k = t / d, c = t % d;
+            rows[k][c] = a.other[(size_t)a.ids[s + k] * d + c];
+        }
+        if (tid < nk) coef[tid] = a.vals[s + tid] - a.w_other[a.ids[s + tid]] - b0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = tid + 256 * q;
+            if (t < d * d) {
+                const int r = t / d, c = t % d;
+                double sacc = acc[q];
+                for (int k = 0; k < nk; ++k) sacc += rows[k][r] * rows[k][c];
+                acc[q] = sacc;
+            }
+        }
+        if (tid < d) {
+            double sb = accb;
+            for (int k = 0; k < nk; ++k) sb += coef[k] * rows[k][tid];
+            accb = sb;
+        }
+        __syncthreads();
+    }
+}
+
+// partial normal equations of one chunk of a long rating list
+__global__ __launch_bounds__(256) void k_als_partial(AlsFitArgs a) {
+    __shared__ double rows[ALS_TILE][ALS_MAXD + 1];
+    __shared__ double coef[ALS_TILE];
+    const int tid = threadIdx.x, d = a.d;
+    for (int64_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
+        const int32_t idx = a.chunk_ent[c];
+        const double b0 = a.w_own[idx] + a.bias;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        double accb = 0.0;
+        __syncthreads();
+        als_accumulate(a, a.chunk_lo[c], a.chunk_hi[c], b0, acc, accb, rows, coef);
+        double* pp = a.partial + (size_t)c * (d * d + d);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int t = tid + 256 * q; if (t < d * d) pp[t] = acc[q]; }
+        if (tid < d) pp[d * d + tid] = accb;
+    }
+}
 
 __global__ __launch_bounds__(256) void k_als_fit(AlsFitArgs a) {
     __shared__ double A[ALS_MAXD][ALS_MAXD + 1];
@@ -44,30 +103,17 @@ __global__ __launch_bounds__(256) void k_als_fit(AlsFitArgs a) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};           // A entries t = tid + 256*q  (d*d <= 1024)
         double accb = 0.0;                               // b entry tid (< d)
         __syncthreads();
-        for (int64_t s = lo; s < hi; s += ALS_TILE) {
-            const int nk = (int)((hi - s < ALS_TILE) ? hi - s : ALS_TILE);
-            for (int t = tid; t < nk * d; t += 256) {
-                const int k = t / d, c = t % d;
-                rows[k][c] = a.other[(size_t)a.ids[s + k] * d + c];
-            }
-            if (tid < nk) coef[tid] = a.vals[s + tid] - a.w_other[a.ids[s + tid]] - b0;
-            __syncthreads();
+        const int32_t nch = a.ccount ? a.ccount[idx] : 0;
+        if (nch > 0) {                                   // a long list: add the chunks' partial sums, in list order
+            const int32_t c0 = a.cfirst[idx];
+            for (int32_t ch = 0; ch < nch; ++ch) {
+                const double* pp = a.partial + (size_t)(c0 + ch) * (d * d + d);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = tid + 256 * q;
-                if (t < d * d) {
-                    const int r = t / d, c = t % d;
-                    double sacc = acc[q];
-                    for (int k = 0; k < nk; ++k) sacc += rows[k][r] * rows[k][c];
-                    acc[q] = sacc;
-                }
+                for (int q = 0; q < 4; ++q) { const int t = tid + 256 * q; if (t < d * d) acc[q] += pp[t]; }
+                if (tid < d) accb += pp[d * d + tid];
             }
-            if (tid < d) {
-                double sb = accb;
-                for (int k = 0; k < nk; ++k) sb += coef[k] * rows[k][tid];
-                accb = sb;
-            }
-            __syncthreads();
+        } else {
+            als_accumulate(a, lo, hi, b0, acc, accb, rows, coef);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -168,6 +214,11 @@ struct tfr_als {
     int64_t *ptr_u = nullptr, *ptr_w = nullptr;
     int32_t *ids_u = nullptr, *ids_w = nullptr, *users = nullptr, *works = nullptr;
     double *val_u = nullptr, *val_w = nullptr;
+    // chunk tables for long rating lists, per side (0 = users, 1 = works)
+    int32_t *cfirst[2] = {nullptr, nullptr}, *ccount[2] = {nullptr, nullptr}, *chunk_ent[2] = {nullptr, nullptr};
+    int64_t *chunk_lo[2] = {nullptr, nullptr}, *chunk_hi[2] = {nullptr, nullptr};
+    int64_t n_chunks[2] = {0, 0};
+    double* partial = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -181,6 +232,8 @@ int tfr_als_destroy(tfr_als* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     void* ps[] = {m->U, m->V, m->Wu, m->Ww, m->ptr_u, m->ptr_w, m->ids_u, m->ids_w, m->users, m->works, m->val_u, m->val_w};
     for (void* p : ps) als_free(p);
+    for (int z = 0; z < 2; ++z) { als_free(m->cfirst[z]); als_free(m->ccount[z]); als_free(m->chunk_ent[z]); als_free(m->chunk_lo[z]); als_free(m->chunk_hi[z]); }
+    als_free(m->partial);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -306,6 +359,45 @@ int tfr_als_load(tfr_als* m, const int64_t* user_ids, const int64_t* work_ids, c
     if (!lu.empty()) ALSCHK(hipMemcpy(m->users, lu.data(), lu.size() * 4, hipMemcpyHostToDevice));
     if (!lw.empty()) ALSCHK(hipMemcpy(m->works, lw.data(), lw.size() * 4, hipMemcpyHostToDevice));
     m->n = n; m->n_users = (int64_t)lu.size(); m->n_works = (int64_t)lw.size();
+    // long lists (a blockbuster item can hold a few per cent of all ratings) would leave one block working
+    // long after the rest of the sweep has finished: cut them into chunks of CH ratings
+    int64_t CH = 2048;
+    if (const char* e = getenv("TFR_ALS_CHUNK")) { const long v = atol(e); if (v >= ALS_TILE) CH = (v / ALS_TILE) * ALS_TILE; }
+    size_t max_chunks = 0;
+    for (int z = 0; z < 2; ++z) {
+        const std::vector<int64_t>& ptr = z == 0 ? pu : pw;
+        const int64_t rows = z == 0 ? m->nu : m->nw;
+        std::vector<int32_t> cf((size_t)rows, -1), cc((size_t)rows, 0), ce;
+        std::vector<int64_t> cl, chh;
+        for (int64_t r = 0; r < rows; ++r) {
+            const int64_t lo = ptr[(size_t)r], hi = ptr[(size_t)r + 1];
+            if (hi - lo <= CH) continue;
+            cf[(size_t)r] = (int32_t)ce.size();
+            for (int64_t s0 = lo; s0 < hi; s0 += CH) {
+                ce.push_back((int32_t)r); cl.push_back(s0); chh.push_back(std::min(hi, s0 + CH));
+                cc[(size_t)r]++;
+            }
+        }
+        als_free(m->cfirst[z]); als_free(m->ccount[z]); als_free(m->chunk_ent[z]); als_free(m->chunk_lo[z]); als_free(m->chunk_hi[z]);
+        m->cfirst[z] = m->ccount[z] = m->chunk_ent[z] = nullptr; m->chunk_lo[z] = m->chunk_hi[z] = nullptr;
+        m->n_chunks[z] = (int64_t)ce.size();
+        ALSCHK(hipMalloc((void**)&m->cfirst[z], (size_t)rows * 4));
+        ALSCHK(hipMalloc((void**)&m->ccount[z], (size_t)rows * 4));
+        ALSCHK(hipMemcpy(m->cfirst[z], cf.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
+        ALSCHK(hipMemcpy(m->ccount[z], cc.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
+        if (!ce.empty()) {
+            ALSCHK(hipMalloc((void**)&m->chunk_ent[z], ce.size() * 4));
+            ALSCHK(hipMalloc((void**)&m->chunk_lo[z], ce.size() * 8));
+            ALSCHK(hipMalloc((void**)&m->chunk_hi[z], ce.size() * 8));
+            ALSCHK(hipMemcpy(m->chunk_ent[z], ce.data(), ce.size() * 4, hipMemcpyHostToDevice));
+            ALSCHK(hipMemcpy(m->chunk_lo[z], cl.data(), ce.size() * 8, hipMemcpyHostToDevice));
+            ALSCHK(hipMemcpy(m->chunk_hi[z], chh.data(), ce.size() * 8, hipMemcpyHostToDevice));
+        }
+        max_chunks = std::max(max_chunks, ce.size());
+    }
+    als_free(m->partial);
+    m->partial = nullptr;
+    if (max_chunks) ALSCHK(hipMalloc((void**)&m->partial, max_chunks * (size_t)(m->d * m->d + m->d) * 8));
     return TFR_OK;
 }
 
@@ -326,9 +418,15 @@ int tfr_als_sweep(tfr_als* m, int32_t n_iterations, float* elapsed_ms) {
         a.bias = m->bias; a.lambda = m->lambda; a.d = m->d;
         a.list = m->users; a.n_list = m->n_users; a.ptr = m->ptr_u; a.ids = m->ids_u; a.vals = m->val_u;
         a.own = m->U; a.w_own = m->Wu; a.other = m->V; a.w_other = m->Ww;
+        a.cfirst = m->cfirst[0]; a.ccount = m->ccount[0]; a.chunk_ent = m->chunk_ent[0]; a.chunk_lo = m->chunk_lo[0];
+        a.chunk_hi = m->chunk_hi[0]; a.n_chunks = m->n_chunks[0]; a.partial = m->partial;
+        if (a.n_list && a.n_chunks) hipLaunchKernelGGL(k_als_partial, dim3((unsigned)std::min<int64_t>(a.n_chunks, 65535)), dim3(256), 0, m->stream, a);
         if (a.n_list) hipLaunchKernelGGL(k_als_fit, dim3((unsigned)std::min<int64_t>(a.n_list, 65535)), dim3(256), 0, m->stream, a);
         a.list = m->works; a.n_list = m->n_works; a.ptr = m->ptr_w; a.ids = m->ids_w; a.vals = m->val_w;
         a.own = m->V; a.w_own = m->Ww; a.other = m->U; a.w_other = m->Wu;
+        a.cfirst = m->cfirst[1]; a.ccount = m->ccount[1]; a.chunk_ent = m->chunk_ent[1]; a.chunk_lo = m->chunk_lo[1];
+        a.chunk_hi = m->chunk_hi[1]; a.n_chunks = m->n_chunks[1]; a.partial = m->partial;
+        if (a.n_list && a.n_chunks) hipLaunchKernelGGL(k_als_partial, dim3((unsigned)std::min<int64_t>(a.n_chunks, 65535)), dim3(256), 0, m->stream, a);
         if (a.n_list) hipLaunchKernelGGL(k_als_fit, dim3((unsigned)std::min<int64_t>(a.n_list, 65535)), dim3(256), 0, m->stream, a);
     }
     (void)hipEventRecord(m->ev1, m->stream);
