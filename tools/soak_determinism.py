@@ -2,7 +2,7 @@
 """One-off soak (GPU box): two identical long runs of the headline workload through the multi-step
 look-ahead path must end in bit-identical tables (no float atomics, fixed summation orders), and a third
 run cut into calls of odd lengths must match too.
-    python tools/soak_determinism.py [steps]"""
+    python tools/soak_determinism.py [steps] [big]"""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,14 +10,19 @@ import tfrecomm_amd as T
 import bench
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-U, I, D, B = 6040, 3952, 64, 10000
-train, _ = bench.synth_movielens(U, I, 1000209)
+big = len(sys.argv) > 2 and sys.argv[2] == "big"     # radix-sort path with the look-ahead stream, lazy Adam
+if big:
+    U, I, D, B = 300000, 40000, 64, 50000
+    train, _ = bench.synth_uniform(U, I, 3000000)
+else:
+    U, I, D, B = 6040, 3952, 64, 10000
+    train, _ = bench.synth_movielens(U, I, 1000209)
 np.random.seed(13575)
-chunk = 2000
+chunk = 500 if big else 2000
 digests = []
 for run in range(3):
     rs = np.random.RandomState(99)
-    m = T.SvdModel(U, I, D, optimizer="adam", adam_mode="tf1", lr=1e-3, reg=0.05)
+    m = T.SvdModel(U, I, D, optimizer="adam", adam_mode="lazy" if big else "tf1", lr=1e-3, reg=0.05)
     m.init_tables(seed=13575)
     m.upload_triples(*train)
     done = 0
