@@ -1361,7 +1361,9 @@ static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nst
         if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr,
                                  loss_out ? m->step_out + (size_t)s * 4 : nullptr,
                                  m->d_ids + (first_step + s) * B,
-                                 s + 1 < nsteps ? m->d_ids + (first_step + s + 1) * B : nullptr))) {
+                                 // look ahead past the end of this call too when more staged batches follow: the
+                                 // next call then starts presorted (the sort is free, hidden in this launch)
+                                 (first_step + s + 2) * B <= m->n_ids ? m->d_ids + (first_step + s + 1) * B : nullptr))) {
             m->pf_valid = false;
             return rc;
         }
