@@ -1503,9 +1503,11 @@ void launch_dense_tiles(const TileDenseLaunch& L, bool write, bool with_fin, int
         const int nt = L.a[0].ntiles;                                                             \
         if (write) {                                                                              \
             if (nt <= 4) TFR_DT_LAUNCH(g, v, true, 4); else if (nt <= 8) TFR_DT_LAUNCH(g, v, true, 8);      \
+            else if (nt <= 10) TFR_DT_LAUNCH(g, v, true, 10);                                               \
             else if (nt <= 12) TFR_DT_LAUNCH(g, v, true, 12); else TFR_DT_LAUNCH(g, v, true, 16);           \
         } else {                                                                                  \
             if (nt <= 4) TFR_DT_LAUNCH(g, v, false, 4); else if (nt <= 8) TFR_DT_LAUNCH(g, v, false, 8);    \
+            else if (nt <= 10) TFR_DT_LAUNCH(g, v, false, 10);                                              \
             else if (nt <= 12) TFR_DT_LAUNCH(g, v, false, 12); else TFR_DT_LAUNCH(g, v, false, 16);         \
         }                                                                                         \
         return;                                                                                   \
