@@ -134,6 +134,25 @@ int tfr_train_steps_resident(tfr_model* m, const int64_t* ids, int64_t batch, in
 int tfr_stage_ids(tfr_model* m, const int64_t* ids, int64_t n);
 int tfr_train_steps_staged(tfr_model* m, int64_t first_step, int64_t batch, int32_t nsteps,
                            float* loss_out);
+/* ---- the minibatch id draw itself on the device (dataio.py:113-117 `next`): NumPy's legacy global
+ *      MT19937 stream (np.random.seed(13575), svd_train_val.py:15) and legacy randint's masked
+ *      rejection, replayed bit for bit by one workgroup, so `ids = np.random.randint(0, N, (batch,))`
+ *      never touches the host.  The state is what np.random.get_state() holds: key[624] and pos.
+ *      high <= 2^32 (NumPy switches to 64-bit draws beyond that). */
+int tfr_rng_seed(tfr_model* m, uint32_t seed);                               /* == np.random.seed(seed) */
+int tfr_rng_set_state(tfr_model* m, const uint32_t* key624, int32_t pos);    /* np.random.get_state()[1:3] */
+int tfr_rng_get_state(tfr_model* m, uint32_t* key624, int32_t* pos);         /* synchronises */
+/* ids_out[count] (host) = np.random.randint(0, high, (count,)); advances the device state. */
+int tfr_draw_ids(tfr_model* m, int64_t high, int64_t count, int64_t* ids_out);
+/* nsteps x { next(iter_train); sess.run(train_op) } (svd_train_val.py:66-72) with every part on the
+ * device: ids drawn from randint(0, n_store_ratings) as above (on a side stream, ahead of the steps
+ * that use them), rows gathered from the resident store, one training step each.  loss_out[nsteps]
+ * may be NULL (then the call does not synchronise). */
+int tfr_train_steps_drawn(tfr_model* m, int64_t batch, int32_t nsteps, float* loss_out);
+/* host-drawn ids (the reference's own np.random.randint call) for ONE step on the resident store:
+ * copied into a pinned ring slot, uploaded and trained on asynchronously - returns without waiting;
+ * id errors surface at the next synchronising call. */
+int tfr_train_step_ids(tfr_model* m, const int64_t* ids, int64_t batch);
 /* forward over store rows [lo, hi): logits_out[hi-lo] host, may be NULL */
 int tfr_forward_resident(tfr_model* m, int64_t lo, int64_t hi, float* logits_out);
 
@@ -255,6 +274,7 @@ enum {
     TFR_K_APPLY = 4,          /* Adam / SGD apply kernels                                   */
     TFR_K_FINALIZE = 5,       /* scalar reduction + bias_global update                      */
     TFR_K_GATHER = 6,         /* resident-store triple gather                               */
+    TFR_K_DRAW = 7,           /* MT19937 id draw (timed on its own side stream)             */
     TFR_K_COUNT = 8
 };
 int tfr_profile(tfr_model* m, int32_t enable);                 /* enable resets the counters */

@@ -29,10 +29,21 @@ def load():
         lib.svdo_set_frozen.argtypes = [C.c_void_p, C.c_uint32]
         lib.svdo_step.restype = C.c_int64
         lib.svdo_step.argtypes = [C.c_void_p]
+        lib.svdo_threads.restype = C.c_int
+        lib.svdo_set_threads.argtypes = [C.c_int]
         lib.svdo_forward.argtypes = [C.c_void_p, _i32p, _i32p, C.c_int64, _f32p]
         lib.svdo_train_step.argtypes = [C.c_void_p, _i32p, _i32p, _f32p, C.c_int64, _f32p, _f32p, _f32p]
         _lib = lib
     return _lib
+
+
+def threads():
+    """Threads the OpenMP loops will use (all host cores unless set_threads / OMP_NUM_THREADS say otherwise)."""
+    return load().svdo_threads()
+
+
+def set_threads(n):
+    load().svdo_set_threads(int(n))
 
 
 class COracle:

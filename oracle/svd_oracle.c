@@ -1,6 +1,12 @@
 /* svd_oracle.c - scalar float32 C restatement of the SVD minibatch step.  TEST INFRASTRUCTURE
  * ONLY: used by tests/ (checked against oracle/svd_oracle.py) and by bench.py's cpu_baseline leg
- * (kind "port", 1 core).  The product never links or loads this file.
+ * (kind "port", all host cores through OpenMP).  The product never links or loads this file.
+ *
+ * Threading keeps every result independent of the thread count except the three batch scalars:
+ * rows are summed per unique row in batch order (exactly the serial order), dense sweeps are
+ * element-wise (TF's five dense passes over a table - decay m, scatter-add, decay v, scatter-add,
+ * update - are walked row by row in one loop: the same operations on every element, in the same order);
+ * loss / regulariser / sum g are added per fixed chunk of 256 ratings, chunks in order.
  *
  * PARITY UNPINNED by reference fixtures (the reference has none for this path; TensorFlow is not
  * installable here) - see the header of oracle/svd_oracle.py.
@@ -21,8 +27,27 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int svdo_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void svdo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 enum { T_MU = 0, T_BU = 1, T_BI = 2, T_P = 3, T_Q = 4 };
+#define CHUNK 256   /* ratings per partial sum of the batch scalars */
 
 typedef struct svdo {
     int64_t U, I;
@@ -40,13 +65,15 @@ typedef struct svdo {
     int64_t cap;
     float *pu, *qi, *dP, *dQ, *dbu, *dbi, *g, *gsum;
     int32_t* uniq;
+    int32_t *slot_of, *start, *order;   /* occurrences grouped by unique slot, batch order inside a slot */
+    float* part;                        /* per-chunk partial scalars */
 } svdo;
 
 static void free_batch(svdo* o) {
     free(o->pu); free(o->qi); free(o->dP); free(o->dQ); free(o->dbu); free(o->dbi); free(o->g);
-    free(o->gsum); free(o->uniq);
+    free(o->gsum); free(o->uniq); free(o->slot_of); free(o->start); free(o->order); free(o->part);
     o->pu = o->qi = o->dP = o->dQ = o->dbu = o->dbi = o->g = o->gsum = NULL;
-    o->uniq = NULL;
+    o->uniq = NULL; o->slot_of = o->start = o->order = NULL; o->part = NULL;
     o->cap = 0;
 }
 
@@ -100,7 +127,10 @@ static int ensure(svdo* o, int64_t B) {
     o->gsum = (float*)malloc(bd * 4);
     o->dbu = (float*)malloc((size_t)B * 4); o->dbi = (float*)malloc((size_t)B * 4);
     o->g = (float*)malloc((size_t)B * 4); o->uniq = (int32_t*)malloc((size_t)B * 4);
-    if (!o->pu || !o->qi || !o->dP || !o->dQ || !o->gsum || !o->dbu || !o->dbi || !o->g || !o->uniq) return -5;
+    o->slot_of = (int32_t*)malloc((size_t)B * 4); o->start = (int32_t*)malloc(((size_t)B + 1) * 4);
+    o->order = (int32_t*)malloc((size_t)B * 4); o->part = (float*)malloc(((size_t)B / CHUNK + 1) * 8 * 4);
+    if (!o->pu || !o->qi || !o->dP || !o->dQ || !o->gsum || !o->dbu || !o->dbi || !o->g || !o->uniq ||
+        !o->slot_of || !o->start || !o->order || !o->part) return -5;
     o->cap = B;
     return 0;
 }
@@ -116,6 +146,7 @@ int svdo_forward(svdo* o, const int32_t* u, const int32_t* it, int64_t B, float*
     if (check_ids(o, u, it, B)) return -2;
     const int D = o->D;
     const float mu = o->w[T_MU][0];
+#pragma omp parallel for schedule(static)
     for (int64_t k = 0; k < B; ++k) {
         const float* p = o->w[T_P] + (size_t)u[k] * D;
         const float* q = o->w[T_Q] + (size_t)it[k] * D;
@@ -132,42 +163,60 @@ int svdo_forward(svdo* o, const int32_t* u, const int32_t* it, int64_t B, float*
 
 static float lr_t(const svdo* o) { return o->lr * sqrtf(1.f - o->b2p) / (1.f - o->b1p); }
 
+/* unique (first-occurrence order) + unsorted_segment_sum (batch order) [TF1-lib]: the slot assignment
+ * is a serial integer pass; each unique row then adds ITS occurrences in batch order - the serial order -
+ * so the sums do not depend on the number of threads.  Returns the number of unique rows. */
+static int64_t group_by_slot(svdo* o, const int32_t* ids, int64_t B, int32_t* slot, int keep) {
+    int64_t nu = 0;
+    for (int64_t k = 0; k < B; ++k) {
+        int32_t s = slot[ids[k]];
+        if (s < 0) { s = (int32_t)nu++; slot[ids[k]] = s; o->uniq[s] = ids[k]; o->start[s] = 0; }
+        o->slot_of[k] = s;
+        o->start[s] += 1;
+    }
+    int32_t run = 0;
+    for (int64_t s = 0; s < nu; ++s) { const int32_t c = o->start[s]; o->start[s] = run; run += c; }
+    o->start[nu] = run;
+    for (int64_t k = 0; k < B; ++k) o->order[o->start[o->slot_of[k]]++] = (int32_t)k;   /* stable */
+    for (int64_t s = nu; s > 0; --s) o->start[s] = o->start[s - 1];
+    o->start[0] = 0;
+    if (!keep) for (int64_t s = 0; s < nu; ++s) slot[o->uniq[s]] = -1;
+    return nu;
+}
+
 /* AdamOptimizer sparse apply on one table [TF1-lib] */
 static void adam_table(svdo* o, int t, int width, const int32_t* ids, const float* occ, int64_t B,
                        int32_t* slot, int64_t rows) {
     if ((o->frozen >> t) & 1) return;
     float* w = o->w[t]; float* m = o->m[t]; float* v = o->v[t];
     const float a = lr_t(o), b1 = o->b1, b2 = o->b2, omb1 = 1.f - o->b1, omb2 = 1.f - o->b2, eps = o->eps;
-    /* unique (first-occurrence order) + unsorted_segment_sum (batch order) */
-    int64_t nu = 0;
-    for (int64_t k = 0; k < B; ++k) {
-        int32_t s = slot[ids[k]];
-        if (s < 0) {
-            s = (int32_t)nu++;
-            slot[ids[k]] = s;
-            o->uniq[s] = ids[k];
-            memset(o->gsum + (size_t)s * width, 0, (size_t)width * 4);
-        }
+    const int64_t nu = group_by_slot(o, ids, B, slot, 1);
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < nu; ++s) {
         float* gs = o->gsum + (size_t)s * width;
-        const float* oc = occ + (size_t)k * width;
-        for (int d = 0; d < width; ++d) gs[d] += oc[d];
+        memset(gs, 0, (size_t)width * 4);
+        for (int32_t j = o->start[s]; j < o->start[s + 1]; ++j) {
+            const float* oc = occ + (size_t)o->order[j] * width;
+            for (int d = 0; d < width; ++d) gs[d] += oc[d];
+        }
     }
-    if (o->adam_mode == 0) {                /* TF1: dense decay, scatter-add, dense update */
-        const int64_t n = rows * width;
-        for (int64_t e = 0; e < n; ++e) m[e] = m[e] * b1;
-        for (int64_t s = 0; s < nu; ++s) {
-            float* mr = m + (size_t)o->uniq[s] * width;
-            const float* gs = o->gsum + (size_t)s * width;
-            for (int d = 0; d < width; ++d) mr[d] += gs[d] * omb1;
+    if (o->adam_mode == 0) {                /* TF1: dense decay, scatter-add, dense update - every row moves */
+#pragma omp parallel for schedule(static)
+        for (int64_t row = 0; row < rows; ++row) {
+            const int32_t sl = slot[row];
+            const float* gs = sl >= 0 ? o->gsum + (size_t)sl * width : NULL;
+            const size_t off = (size_t)row * width;
+            for (int d = 0; d < width; ++d) {
+                float mm = m[off + d] * b1;
+                if (gs) mm += gs[d] * omb1;
+                float vv = v[off + d] * b2;
+                if (gs) vv += (gs[d] * gs[d]) * omb2;
+                m[off + d] = mm; v[off + d] = vv;
+                w[off + d] -= a * mm / (sqrtf(vv) + eps);
+            }
         }
-        for (int64_t e = 0; e < n; ++e) v[e] = v[e] * b2;
-        for (int64_t s = 0; s < nu; ++s) {
-            float* vr = v + (size_t)o->uniq[s] * width;
-            const float* gs = o->gsum + (size_t)s * width;
-            for (int d = 0; d < width; ++d) vr[d] += (gs[d] * gs[d]) * omb2;
-        }
-        for (int64_t e = 0; e < n; ++e) w[e] -= a * m[e] / (sqrtf(v[e]) + eps);
     } else {                                /* lazy: touched rows only */
+#pragma omp parallel for schedule(static)
         for (int64_t s = 0; s < nu; ++s) {
             const size_t off = (size_t)o->uniq[s] * width;
             const float* gs = o->gsum + (size_t)s * width;
@@ -182,14 +231,19 @@ static void adam_table(svdo* o, int t, int width, const int32_t* ids, const floa
     for (int64_t s = 0; s < nu; ++s) slot[o->uniq[s]] = -1;
 }
 
-/* GradientDescentOptimizer sparse apply = scatter_sub [TF1-lib] */
-static void sgd_table(svdo* o, int t, int width, const int32_t* ids, const float* occ, int64_t B) {
+/* GradientDescentOptimizer sparse apply = scatter_sub [TF1-lib]: duplicates accumulate in batch order;
+ * rows are independent, so each row replays its own occurrences in that order */
+static void sgd_table(svdo* o, int t, int width, const int32_t* ids, const float* occ, int64_t B, int32_t* slot) {
     if ((o->frozen >> t) & 1) return;
     float* w = o->w[t];
-    for (int64_t k = 0; k < B; ++k) {
-        float* wr = w + (size_t)ids[k] * width;
-        const float* oc = occ + (size_t)k * width;
-        for (int d = 0; d < width; ++d) wr[d] -= o->lr * oc[d];
+    const int64_t nu = group_by_slot(o, ids, B, slot, 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < nu; ++s) {
+        float* wr = w + (size_t)o->uniq[s] * width;
+        for (int32_t j = o->start[s]; j < o->start[s + 1]; ++j) {
+            const float* oc = occ + (size_t)o->order[j] * width;
+            for (int d = 0; d < width; ++d) wr[d] -= o->lr * oc[d];
+        }
     }
 }
 
@@ -202,48 +256,60 @@ int svdo_train_step(svdo* o, const int32_t* u, const int32_t* it, const float* r
     const float lam = o->reg;
     const float mu = o->w[T_MU][0];
     float loss = 0.f, reg = 0.f, l2u = 0.f, l2i = 0.f, l2bu = 0.f, l2bi = 0.f, dmu = 0.f;
-    /* gathers (materialised, like feat_users / feat_items) */
-    for (int64_t k = 0; k < B; ++k) {
-        memcpy(o->pu + (size_t)k * D, o->w[T_P] + (size_t)u[k] * D, (size_t)D * 4);
-        memcpy(o->qi + (size_t)k * D, o->w[T_Q] + (size_t)it[k] * D, (size_t)D * 4);
-    }
-    for (int64_t k = 0; k < B; ++k) {
-        const float* p = o->pu + (size_t)k * D;
-        const float* q = o->qi + (size_t)k * D;
-        const float bu = o->w[T_BU][u[k]], bi = o->w[T_BI][it[k]];
-        float s = 0.f;
-        for (int d = 0; d < D; ++d) {
-            s += p[d] * (o->item_abs ? fabsf(q[d]) : q[d]);
-            l2u += p[d] * p[d];
-            l2i += q[d] * q[d];
+    const int64_t nchunk = (B + CHUNK - 1) / CHUNK;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nchunk; ++c) {
+        float closs = 0.f, cl2u = 0.f, cl2i = 0.f, cl2bu = 0.f, cl2bi = 0.f, cdmu = 0.f;
+        const int64_t k1 = (c + 1) * CHUNK < B ? (c + 1) * CHUNK : B;
+        /* gathers (materialised, like feat_users / feat_items) */
+        for (int64_t k = c * CHUNK; k < k1; ++k) {
+            memcpy(o->pu + (size_t)k * D, o->w[T_P] + (size_t)u[k] * D, (size_t)D * 4);
+            memcpy(o->qi + (size_t)k * D, o->w[T_Q] + (size_t)it[k] * D, (size_t)D * 4);
         }
-        const float x = ((s + mu) + bu) + bi;
-        if (logits_out) logits_out[k] = x;
-        float g;
-        if (o->loss == 0) { g = x - r[k]; loss += g * g; }
-        else {
-            g = 1.f / (1.f + expf(-x)) - r[k];
-            loss += fmaxf(x, 0.f) - x * r[k] + log1pf(expf(-fabsf(x)));
-        }
-        o->g[k] = g;
-        dmu += g;
-        l2bu += bu * bu; l2bi += bi * bi;
-        /* per-occurrence gradient values */
-        float* dp = o->dP + (size_t)k * D;
-        float* dq = o->dQ + (size_t)k * D;
-        for (int d = 0; d < D; ++d) {
-            const float qd = q[d];
-            if (o->item_abs) {
-                const float sg = (qd > 0.f) ? 1.f : ((qd < 0.f) ? -1.f : 0.f);
-                dp[d] = g * fabsf(qd) + lam * p[d];
-                dq[d] = g * p[d] * sg + lam * qd;
-            } else {
-                dp[d] = g * qd + lam * p[d];
-                dq[d] = g * p[d] + lam * qd;
+        for (int64_t k = c * CHUNK; k < k1; ++k) {
+            const float* p = o->pu + (size_t)k * D;
+            const float* q = o->qi + (size_t)k * D;
+            const float bu = o->w[T_BU][u[k]], bi = o->w[T_BI][it[k]];
+            float s = 0.f;
+            for (int d = 0; d < D; ++d) {
+                s += p[d] * (o->item_abs ? fabsf(q[d]) : q[d]);
+                cl2u += p[d] * p[d];
+                cl2i += q[d] * q[d];
             }
+            const float x = ((s + mu) + bu) + bi;
+            if (logits_out) logits_out[k] = x;
+            float g;
+            if (o->loss == 0) { g = x - r[k]; closs += g * g; }
+            else {
+                g = 1.f / (1.f + expf(-x)) - r[k];
+                closs += fmaxf(x, 0.f) - x * r[k] + log1pf(expf(-fabsf(x)));
+            }
+            o->g[k] = g;
+            cdmu += g;
+            cl2bu += bu * bu; cl2bi += bi * bi;
+            /* per-occurrence gradient values */
+            float* dp = o->dP + (size_t)k * D;
+            float* dq = o->dQ + (size_t)k * D;
+            for (int d = 0; d < D; ++d) {
+                const float qd = q[d];
+                if (o->item_abs) {
+                    const float sg = (qd > 0.f) ? 1.f : ((qd < 0.f) ? -1.f : 0.f);
+                    dp[d] = g * fabsf(qd) + lam * p[d];
+                    dq[d] = g * p[d] * sg + lam * qd;
+                } else {
+                    dp[d] = g * qd + lam * p[d];
+                    dq[d] = g * p[d] + lam * qd;
+                }
+            }
+            o->dbu[k] = o->reg_bias ? g + lam * bu : g;
+            o->dbi[k] = o->reg_bias ? g + lam * bi : g;
         }
-        o->dbu[k] = o->reg_bias ? g + lam * bu : g;
-        o->dbi[k] = o->reg_bias ? g + lam * bi : g;
+        float* pc = o->part + (size_t)c * 8;
+        pc[0] = closs; pc[1] = cl2u; pc[2] = cl2i; pc[3] = cl2bu; pc[4] = cl2bi; pc[5] = cdmu;
+    }
+    for (int64_t c = 0; c < nchunk; ++c) {                /* chunks in order: independent of the thread count */
+        const float* pc = o->part + (size_t)c * 8;
+        loss += pc[0]; l2u += pc[1]; l2i += pc[2]; l2bu += pc[3]; l2bi += pc[4]; dmu += pc[5];
     }
     if (o->loss == 0) loss *= 0.5f;                       /* tf.nn.l2_loss = sum(x^2)/2 */
     reg = 0.5f * l2u + 0.5f * l2i;
@@ -265,10 +331,10 @@ int svdo_train_step(svdo* o, const int32_t* u, const int32_t* it, const float* r
         o->b1p *= o->b1;
         o->b2p *= o->b2;
     } else {
-        sgd_table(o, T_P, D, u, o->dP, B);
-        sgd_table(o, T_Q, D, it, o->dQ, B);
-        sgd_table(o, T_BU, 1, u, o->dbu, B);
-        sgd_table(o, T_BI, 1, it, o->dbi, B);
+        sgd_table(o, T_P, D, u, o->dP, B, o->slot_u);
+        sgd_table(o, T_Q, D, it, o->dQ, B, o->slot_i);
+        sgd_table(o, T_BU, 1, u, o->dbu, B, o->slot_u);
+        sgd_table(o, T_BI, 1, it, o->dbi, B, o->slot_i);
         if (!((o->frozen >> T_MU) & 1)) o->w[T_MU][0] -= o->lr * dmu;
     }
     o->step += 1;

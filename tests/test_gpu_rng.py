@@ -1,0 +1,140 @@
+"""The minibatch id draw on the device (rng.hip, include/tfrecomm.h "id draw"): NumPy's legacy
+``np.random.randint(0, N, (B,))`` (dataio.py:115, seeded at svd_train_val.py:15) replayed bit for bit.
+
+Index work is a bit-exact target: checked against NumPy itself, against the id streams the REAL
+reference dataio.py produced (tests/golden/iter_streams.npz) and, end to end, by training on
+device-drawn ids vs the same steps with host-drawn ids.  Nothing here reads /root/reference."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import tfrecomm_amd as T
+from tfrecomm_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(m):
+    h = hashlib.sha256()
+    for k, v in sorted(m.tables().items()):
+        h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture
+def model():
+    with T.SvdModel(50, 40, 8, device=0) as m:
+        yield m
+
+
+def test_draw_matches_numpy_and_leaves_numpy_state(model):
+    m = model
+    np.random.seed(13575)                                        # svd_train_val.py:15
+    m.rng_seed(13575)
+    # ranges around powers of two (no rejection / ~50 % rejection), tiny, ML-1M's 900188, 90M; counts that
+    # end inside, exactly at and just past a 624-word block
+    cases = [(900188, 10000), (7, 5), (1 << 20, 3000), ((1 << 20) + 1, 3000), (90_000_000, 5000), (2, 1), (2, 623), (2, 1),
+             (2, 624), (2, 625), (1, 17), (3, 0), ((1 << 32) - 1, 2000), (1 << 32, 1500), (1000209, 262144)]
+    for high, count in cases:
+        want = np.random.randint(0, high, (count,))
+        got = m.draw_ids(high, count)
+        assert got.dtype == want.dtype == np.int64
+        assert np.array_equal(got, want), (high, count)
+        key, pos = m.rng_get_state()
+        st = np.random.get_state()
+        assert pos == st[2] and np.array_equal(key, st[1]), (high, count)
+    # hand-over both ways: host draws, device continues, host continues
+    np.random.randint(0, 77, 1000)
+    m.rng_from_numpy()
+    a = m.draw_ids(12345, 4321)
+    assert np.array_equal(a, np.random.randint(0, 12345, 4321))
+    np.random.seed(1)
+    m.rng_to_numpy()                                             # back to where the device is
+    assert np.array_equal(np.random.randint(0, 999, 100), m.draw_ids(999, 100))
+
+
+def test_draw_matches_the_reference_iterators_own_streams(model, golden):
+    """tests/golden/iter_streams.npz holds the ids the real /root/reference/dataio.py ShuffleIterator drew."""
+    g = golden("iter_streams.npz")
+    keys = sorted({k.split("/")[0] for k in g.files if k.startswith("shuffle_")})
+    assert len(keys) == 3
+    for key in keys:
+        N, B = int(key.split("_")[1][1:]), int(key.split("_")[2][1:])
+        ids = g[key + "/ids"]
+        model.rng_seed(int(g[key + "/seed"]))
+        for k in range(ids.shape[0]):
+            assert np.array_equal(model.draw_ids(N, B), ids[k]), (key, k)
+
+
+def test_errors(model):
+    with pytest.raises(T.TfrError) as e:
+        model.draw_ids(10, 5)                                    # no state yet
+    assert e.value.code == L.ERR_STATE
+    model.rng_seed(1)
+    for bad in (0, -3, (1 << 32) + 1):
+        with pytest.raises(T.TfrError) as e:
+            model.draw_ids(bad, 5)
+        assert e.value.code == L.ERR_ARG
+    with pytest.raises(T.TfrError) as e:
+        model.train_steps_drawn(16, 2)                           # no resident store
+    assert e.value.code == L.ERR_STATE
+
+
+@pytest.mark.parametrize("U,I,D,B,N,steps,mode", [
+    (6040, 3952, 64, 10000, 900188, 7, "tf1"),                   # the headline shape (k_tile_step + look-ahead sort)
+    (300, 200, 20, 1000, 5000, 5, "tf1"),
+    (300, 200, 20, 700, 5000, 4, "lazy"),
+    (40000, 30000, 32, 4096, 200000, 5, "lazy"),                 # big-table path: gather + radix sort on the side stream
+    (40000, 30000, 32, 4096, 200000, 3, "tf1"),
+    (120, 90, 8, 300, 1, 3, "tf1"),                              # a one-rating store: every id is 0, no draw consumed
+])
+def test_drawn_steps_equal_host_drawn_steps(U, I, D, B, N, steps, mode):
+    rs = np.random.RandomState(3)
+    su, si = rs.randint(0, U, N).astype(np.int32), rs.randint(0, I, N).astype(np.int32)
+    sr = rs.randint(1, 6, N).astype(np.float32)
+    digests, losses = [], []
+    for device_draw in (False, True):
+        with T.SvdModel(U, I, D, adam_mode=mode, device=0) as m:
+            m.init_tables(seed=5)
+            m.upload_triples(su, si, sr)
+            np.random.seed(13575)
+            if device_draw:
+                m.rng_from_numpy()
+                loss = np.concatenate([m.train_steps_drawn(B, 2, want_loss=True), m.train_steps_drawn(B, steps - 2, want_loss=True)])
+                m.rng_to_numpy()
+            else:
+                ids = np.random.randint(0, N, (steps, B))        # dataio.py:115, one draw per step
+                loss = m.train_steps_resident(ids, B)
+            tail = np.random.randint(0, 1 << 30, 8)              # the host stream continues identically
+            digests.append((_digest(m), tail.tolist()))
+            losses.append(loss)
+    assert digests[0] == digests[1]
+    assert np.array_equal(losses[0], losses[1])
+
+
+def test_host_ids_async_steps_equal_resident_steps():
+    U, I, D, B, N, steps = 6040, 3952, 64, 10000, 900188, 6
+    rs = np.random.RandomState(4)
+    su, si = rs.randint(0, U, N).astype(np.int32), rs.randint(0, I, N).astype(np.int32)
+    sr = rs.randint(1, 6, N).astype(np.float32)
+    ids = rs.randint(0, N, (steps, B))
+    out = []
+    for ring in (False, True):
+        with T.SvdModel(U, I, D, device=0) as m:
+            m.init_tables(seed=5)
+            m.upload_triples(su, si, sr)
+            if ring:
+                for s in range(steps):
+                    m.train_step_ids(ids[s])                     # no host sync between steps
+                m.sync()
+            else:
+                m.train_steps_resident(ids, B)
+            out.append(_digest(m))
+    assert out[0] == out[1]
+    with T.SvdModel(U, I, D, device=0) as m:
+        m.init_tables(seed=5)
+        m.upload_triples(su, si, sr)
+        m.train_step_ids(np.array([0, N], dtype=np.int64))       # out-of-range store index: reported at the next sync
+        with pytest.raises(IndexError):
+            m.sync()

@@ -20,8 +20,8 @@ SLOT_M, SLOT_V = 8, 16
 LOSS = {"mse": 0, "nll": 1}
 OPTIMIZER = {"adam": 0, "sgd": 1}
 ADAM_MODE = {"tf1": 0, "lazy": 1}
-K_FORWARD, K_SORT, K_REDUCE_ITEM, K_REDUCE_USER, K_APPLY, K_FINALIZE, K_GATHER = range(7)
-KERNEL_NAMES = ["forward", "sort", "reduce_item", "reduce_user", "apply", "finalize", "gather"]
+K_FORWARD, K_SORT, K_REDUCE_ITEM, K_REDUCE_USER, K_APPLY, K_FINALIZE, K_GATHER, K_DRAW = range(8)
+KERNEL_NAMES = ["forward", "sort", "reduce_item", "reduce_user", "apply", "finalize", "gather", "draw"]
 
 
 class TfrOpts(C.Structure):
@@ -71,6 +71,12 @@ SIGNATURES = {
     "tfr_stage_ids": (C.c_int, [_p, _i64p, C.c_int64]),
     "tfr_train_steps_staged": (C.c_int, [_p, C.c_int64, C.c_int64, C.c_int32, _f32p]),
     "tfr_forward_resident": (C.c_int, [_p, C.c_int64, C.c_int64, _f32p]),
+    "tfr_rng_seed": (C.c_int, [_p, C.c_uint32]),
+    "tfr_rng_set_state": (C.c_int, [_p, C.POINTER(C.c_uint32), C.c_int32]),
+    "tfr_rng_get_state": (C.c_int, [_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "tfr_draw_ids": (C.c_int, [_p, C.c_int64, C.c_int64, _i64p]),
+    "tfr_train_steps_drawn": (C.c_int, [_p, C.c_int64, C.c_int32, _f32p]),
+    "tfr_train_step_ids": (C.c_int, [_p, _i64p, C.c_int64]),
     "tfr_forward_dev": (C.c_int, [_p, _p, _p, C.c_int64, _p]),
     "tfr_train_step_dev": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p]),
     "tfr_table_devptr": (C.c_int, [_p, C.c_int32, C.POINTER(_p), _i64p]),

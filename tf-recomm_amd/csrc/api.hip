@@ -89,6 +89,18 @@ struct tfr_model {
     int64_t N = 0;
     int64_t* d_ids = nullptr;
     int64_t n_ids = 0;
+    int64_t d_ids_cap = 0;
+    // device id draw (rng.hip): NumPy's MT19937 state {key[624], pos}; draws run on their own stream, ahead
+    // of the steps that consume them; one event per drawn chunk
+    uint32_t* d_rng = nullptr;
+    bool rng_set = false;
+    hipStream_t stream3 = nullptr;
+    std::vector<hipEvent_t> chunk_ev;
+    hipEvent_t ev_ids_free = nullptr;
+    // host-drawn ids, one step at a time, without a host sync: pinned ring + device ring
+    static const int HRING = 4;
+    int64_t* h_ring = nullptr; int64_t* d_ring = nullptr; int64_t ring_cap = 0; int ring_pos = 0;
+    hipEvent_t ring_ev[HRING] = {nullptr, nullptr, nullptr, nullptr};
     // resident validation set (svd_train_val.py:33-38: the whole set is one batch)
     int32_t *ev_u = nullptr, *ev_i = nullptr;
     float* ev_r = nullptr;
@@ -307,6 +319,12 @@ int tfr_destroy(tfr_model* m) {
     dfree(m->store);
     dfree(m->d_ids); dfree(m->ev_u); dfree(m->ev_i); dfree(m->ev_r);
     if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); }
+    if (m->stream3) { (void)hipStreamSynchronize(m->stream3); (void)hipStreamDestroy(m->stream3); }
+    for (auto e : m->chunk_ev) (void)hipEventDestroy(e);
+    if (m->ev_ids_free) (void)hipEventDestroy(m->ev_ids_free);
+    dfree(m->d_rng); dfree(m->d_ring);
+    if (m->h_ring) (void)hipHostFree(m->h_ring);
+    for (int z = 0; z < tfr_model::HRING; ++z) if (m->ring_ev[z]) (void)hipEventDestroy(m->ring_ev[z]);
     for (int z = 0; z < 2; ++z) { if (m->ev_sorted[z]) (void)hipEventDestroy(m->ev_sorted[z]); if (m->ev_free[z]) (void)hipEventDestroy(m->ev_free[z]); }
     if (m->ev_first) (void)hipEventDestroy(m->ev_first);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
@@ -1247,14 +1265,26 @@ int tfr_init_tables(tfr_model* m, uint64_t seed, float fstd, float bstd) {
     return TFR_OK;
 }
 
+// room for n staged ids (contents undefined afterwards); the stream must be idle
+static int ensure_ids(tfr_model* m, int64_t n) {
+    m->n_ids = 0; m->pf_valid = false;
+    if (n > m->d_ids_cap) {
+        if (m->stream3) HIPCHK(hipStreamSynchronize(m->stream3));
+        dfree(m->d_ids);
+        m->d_ids = nullptr; m->d_ids_cap = 0;
+        int rc;
+        if ((rc = dmalloc(&m->d_ids, (size_t)n))) return rc;
+        m->d_ids_cap = n;
+    }
+    return TFR_OK;
+}
+
 int tfr_stage_ids(tfr_model* m, const int64_t* ids, int64_t n) {
     MODEL_ENTER(m);
     if (n < 1 || !ids) return fail(TFR_ERR_ARG, "stage_ids: need n >= 1 and non-null ids");
     HIPCHK(hipStreamSynchronize(m->stream));
-    dfree(m->d_ids);
-    m->d_ids = nullptr; m->n_ids = 0; m->pf_valid = false;
     int rc;
-    if ((rc = dmalloc(&m->d_ids, (size_t)n))) return rc;
+    if ((rc = ensure_ids(m, n))) return rc;
     HIPCHK(hipMemcpyAsync(m->d_ids, ids, (size_t)n * 8, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     m->n_ids = n;
@@ -1305,7 +1335,24 @@ static int ensure_lookahead(tfr_model* m) {
 // Big tables, touched-rows optimiser: gather + radix sort (+ id range check) of batch s+1 do not depend
 // on the tables, are a few small latency-bound launches, and would otherwise head every step; they run
 // on a second stream into the alternate buffer set while step s's HBM-bound kernels own the CUs.
-static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, int32_t nsteps, float* loss_out) {
+// Steps whose ids are still being drawn on the side stream (tfr_train_steps_drawn): need(step, stream) makes
+// `stream` wait for the chunk that holds that step's ids.  NULL when the ids were staged by the host.
+struct IdsReady {
+    tfr_model* m; int64_t chunk0, chunk; int nchunks;
+    int waited[2] = {-1, -1};                              // highest chunk waited for: [0] main stream, [1] stream2
+    int chunk_of(int64_t step) const { return step < chunk0 ? 0 : 1 + (int)((step - chunk0) / chunk); }
+    int need(int64_t step, hipStream_t st, int which) {
+        int c = chunk_of(step);
+        if (c >= nchunks) c = nchunks - 1;
+        if (c > waited[which]) {                           // chunks complete in order on the draw stream
+            if (hipStreamWaitEvent(st, m->chunk_ev[c], 0) != hipSuccess) return fail(TFR_ERR_HIP, "hipStreamWaitEvent failed");
+            waited[which] = c;
+        }
+        return TFR_OK;
+    }
+};
+
+static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, int32_t nsteps, float* loss_out, IdsReady* ready) {
     int rc;
     if ((rc = ensure_lookahead(m))) return rc;
     hipStream_t main_s = m->stream;
@@ -1315,6 +1362,7 @@ static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, i
     bool fd0 = false;
     auto sort_batch = [&](int64_t step) -> int {           // into the buffer set the model currently points at
         const int32_t* du = m->d_u; const int32_t* di = m->d_i; const float* dr = m->d_r;
+        if (ready) { const int e = ready->need(first_step + step, m->stream, m->stream == main_s ? 0 : 1); if (e) return e; }
         return front_and_sort(m, du, di, dr, B, nullptr, m->d_ids + (first_step + step) * B, fdummy, nb0, fd0, false, true);
     };
     if ((rc = sort_batch(0))) return rc;
@@ -1343,7 +1391,7 @@ static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, i
     return TFR_OK;
 }
 
-static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nsteps, float* loss_out) {
+static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nsteps, float* loss_out, IdsReady* ready = nullptr) {
     int rc;
     if ((rc = ensure_capacity(m, B))) return rc;
     if (loss_out && (rc = ensure_step_out(m, nsteps))) return rc;
@@ -1352,12 +1400,13 @@ static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nst
     static int no_ahead = -1;                              // TFR_NO_LOOKAHEAD=1: A/B switch
     if (no_ahead < 0) { const char* e = getenv("TFR_NO_LOOKAHEAD"); no_ahead = (e && e[0] == '1') ? 1 : 0; }
     if (nsteps > 1 && fwd_in_reduce(m, B) && !m->prof && !no_ahead) {
-        if ((rc = staged_steps_lookahead(m, first_step, B, nsteps, loss_out))) {
+        if ((rc = staged_steps_lookahead(m, first_step, B, nsteps, loss_out, ready))) {
             (void)hipStreamSynchronize(m->stream2);
             return rc;
         }
     } else {
     for (int32_t s = 0; s < nsteps; ++s) {
+        if (ready && (rc = ready->need(first_step + s + ((first_step + s + 2) * B <= m->n_ids ? 1 : 0), m->stream, 0))) return rc;
         if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr,
                                  loss_out ? m->step_out + (size_t)s * 4 : nullptr,
                                  m->d_ids + (first_step + s) * B,
@@ -1401,6 +1450,163 @@ int tfr_train_steps_resident(tfr_model* m, const int64_t* ids, int64_t B, int32_
     int rc = tfr_stage_ids(m, ids, B * nsteps);
     if (rc) return rc;
     return staged_steps(m, 0, B, nsteps, loss_out);
+}
+
+// ---- device id draw (rng.hip) ------------------------------------------------------------
+static int ensure_rng(tfr_model* m) {
+    if (!m->d_rng) {
+        int rc;
+        if ((rc = dmalloc(&m->d_rng, 625))) return rc;
+    }
+    if (!m->stream3) {
+        HIPCHK(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_ids_free, hipEventDisableTiming));
+    }
+    return TFR_OK;
+}
+
+int tfr_rng_set_state(tfr_model* m, const uint32_t* key, int32_t pos) {
+    MODEL_ENTER(m);
+    if (!key || pos < 0 || pos > 624) return fail(TFR_ERR_ARG, "rng_set_state: need key[624] and pos in [0, 624]");
+    int rc;
+    if ((rc = ensure_rng(m))) return rc;
+    HIPCHK(hipStreamSynchronize(m->stream3));
+    uint32_t h[625];
+    memcpy(h, key, 624 * 4);
+    h[624] = (uint32_t)pos;
+    HIPCHK(hipMemcpy(m->d_rng, h, sizeof(h), hipMemcpyHostToDevice));
+    m->rng_set = true;
+    return TFR_OK;
+}
+
+int tfr_rng_seed(tfr_model* m, uint32_t seed) {
+    // init_genrand of MT19937 = what np.random.seed(int) does [NumPy-lib: _legacy_seeding -> mt19937_seed]
+    uint32_t key[624];
+    key[0] = seed;
+    for (int i = 1; i < 624; ++i) key[i] = 1812433253u * (key[i - 1] ^ (key[i - 1] >> 30)) + (uint32_t)i;
+    return tfr_rng_set_state(m, key, 624);
+}
+
+int tfr_rng_get_state(tfr_model* m, uint32_t* key, int32_t* pos) {
+    MODEL_ENTER(m);
+    if (!m->rng_set) return fail(TFR_ERR_STATE, "no generator state: call tfr_rng_seed / tfr_rng_set_state first");
+    HIPCHK(hipStreamSynchronize(m->stream3));
+    uint32_t h[625];
+    HIPCHK(hipMemcpy(h, m->d_rng, sizeof(h), hipMemcpyDeviceToHost));
+    if (key) memcpy(key, h, 624 * 4);
+    if (pos) *pos = (int32_t)h[624];
+    return TFR_OK;
+}
+
+// mask of legacy randint's rejection loop: smallest 2^k - 1 >= rng
+static uint32_t mask_for(uint32_t rng) {
+    uint32_t mk = rng;
+    mk |= mk >> 1; mk |= mk >> 2; mk |= mk >> 4; mk |= mk >> 8; mk |= mk >> 16;
+    return mk;
+}
+
+static int check_high(int64_t high) {
+    if (high < 1 || high > ((int64_t)1 << 32))
+        return fail(TFR_ERR_ARG, "randint(0, high): high must be in [1, 2^32] (NumPy draws 64-bit words beyond that)");
+    return TFR_OK;
+}
+
+int tfr_draw_ids(tfr_model* m, int64_t high, int64_t count, int64_t* ids_out) {
+    MODEL_ENTER(m);
+    int rc;
+    if ((rc = check_high(high))) return rc;
+    if (count < 0 || (count > 0 && !ids_out)) return fail(TFR_ERR_ARG, "draw_ids: bad count / null output");
+    if (!m->rng_set) return fail(TFR_ERR_STATE, "no generator state: call tfr_rng_seed / tfr_rng_set_state first");
+    if (count == 0) return TFR_OK;
+    if (high == 1) { memset(ids_out, 0, (size_t)count * 8); return TFR_OK; }    // rng == 0: no draw is consumed
+    int64_t* d = nullptr;
+    if ((rc = dmalloc(&d, (size_t)count))) return rc;
+    const uint32_t rng = (uint32_t)(high - 1);
+    launch_mt_draw(m->d_rng, d, count, rng, mask_for(rng), m->stream3);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ids_out, d, (size_t)count * 8, hipMemcpyDeviceToHost, m->stream3);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream3);
+    dfree(d);
+    if (e != hipSuccess) return fail(TFR_ERR_HIP, "draw_ids: %s", hipGetErrorString(e));
+    return TFR_OK;
+}
+
+int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_out) {
+    MODEL_ENTER(m);
+    if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples first");
+    if (!m->rng_set) return fail(TFR_ERR_STATE, "no generator state: call tfr_rng_seed / tfr_rng_set_state first");
+    if (B < 1 || nsteps < 0) return fail(TFR_ERR_ARG, "bad batch/nsteps");
+    if (nsteps == 0) return TFR_OK;
+    int rc;
+    if ((rc = check_high(m->N))) return rc;
+    const int64_t total = B * (int64_t)nsteps;
+    if (total > m->d_ids_cap) {                            // (re)allocation: nothing may still read the old buffer
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if ((rc = ensure_ids(m, total))) return rc;
+    }
+    m->pf_valid = false;                                   // the buffer's contents change: no published look-ahead sort survives
+    m->n_ids = total;
+    // the draws overwrite the id buffer: they may start once every step already queued has read it
+    HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));
+    HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));
+    // chunk 0 = the first two steps (a step's launch also sorts the batch after it), then ~128K ids per chunk
+    IdsReady ready;
+    ready.m = m;
+    ready.chunk0 = nsteps < 2 ? nsteps : 2;
+    ready.chunk = B >= 131072 ? 1 : 131072 / B;
+    ready.nchunks = 1 + (int)((nsteps - ready.chunk0 + ready.chunk - 1) / ready.chunk);
+    while ((int)m->chunk_ev.size() < ready.nchunks) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->chunk_ev.push_back(e);
+    }
+    const uint32_t rng = (uint32_t)(m->N - 1);
+    if (rng == 0) HIPCHK(hipMemsetAsync(m->d_ids, 0, (size_t)total * 8, m->stream3));
+    for (int c = 0; c < ready.nchunks; ++c) {
+        const int64_t s0 = c == 0 ? 0 : ready.chunk0 + (int64_t)(c - 1) * ready.chunk;
+        int64_t s1 = c == 0 ? ready.chunk0 : s0 + ready.chunk;
+        if (s1 > nsteps) s1 = nsteps;
+        if (rng != 0) launch_mt_draw(m->d_rng, m->d_ids + s0 * B, (s1 - s0) * B, rng, mask_for(rng), m->stream3);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(m->chunk_ev[c], m->stream3));
+    }
+    return staged_steps(m, 0, B, nsteps, loss_out, &ready);
+}
+
+static int ensure_ring(tfr_model* m, int64_t B) {
+    if (B <= m->ring_cap) return TFR_OK;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    dfree(m->d_ring); m->d_ring = nullptr;
+    if (m->h_ring) (void)hipHostFree(m->h_ring);
+    m->h_ring = nullptr; m->ring_cap = 0;
+    int64_t cap = 1024;
+    while (cap < B) cap *= 2;
+    int rc;
+    if ((rc = dmalloc(&m->d_ring, (size_t)cap * tfr_model::HRING))) return rc;
+    HIPCHK(hipHostMalloc((void**)&m->h_ring, (size_t)cap * tfr_model::HRING * 8, hipHostMallocDefault));
+    for (int z = 0; z < tfr_model::HRING; ++z)
+        if (!m->ring_ev[z]) HIPCHK(hipEventCreateWithFlags(&m->ring_ev[z], hipEventDisableTiming));
+    m->ring_cap = cap;
+    return TFR_OK;
+}
+
+int tfr_train_step_ids(tfr_model* m, const int64_t* ids, int64_t B) {
+    MODEL_ENTER(m);
+    if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples first");
+    if (B < 1 || !ids) return fail(TFR_ERR_ARG, "bad batch / null ids");
+    int rc;
+    if ((rc = ensure_capacity(m, B))) return rc;
+    if ((rc = ensure_ring(m, B))) return rc;
+    const int z = m->ring_pos;
+    m->ring_pos = (z + 1) % tfr_model::HRING;
+    HIPCHK(hipEventSynchronize(m->ring_ev[z]));            // the copy that last used this pinned slot has left it
+    int64_t* h = m->h_ring + (size_t)z * m->ring_cap;
+    int64_t* d = m->d_ring + (size_t)z * m->ring_cap;
+    memcpy(h, ids, (size_t)B * 8);
+    HIPCHK(hipMemcpyAsync(d, h, (size_t)B * 8, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipEventRecord(m->ring_ev[z], m->stream));
+    m->pf_valid = false;
+    return run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr, nullptr, d, nullptr);
 }
 
 int tfr_forward_resident(tfr_model* m, int64_t lo, int64_t hi, float* logits_out) {

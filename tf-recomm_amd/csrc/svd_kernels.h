@@ -191,6 +191,9 @@ void launch_finalize(const FinArgs& a, hipStream_t s);
 void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s);
 void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s);
 
+// rng.hip: NumPy's legacy randint(0, rng + 1, (need,)) from the MT19937 state {key[624], pos} at d_state
+void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rng, uint32_t mask, hipStream_t s);
+
 // sort.hip
 constexpr int CSORT_TILE = 1024;
 constexpr int CSORT_MAX_BINS = 16384;          // 64 KB of LDS counters

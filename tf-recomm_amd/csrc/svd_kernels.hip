@@ -151,9 +151,18 @@ __device__ __forceinline__ void block_sum_pieces(const float (&val)[3 * EPG], fl
 //                 (svd_train_val.py:144-149)
 // A lane group owns one rating at a time; UNR ratings are in flight per group so each
 // lane has 2*UNR independent 16-byte loads outstanding.
-template <int G, int VEC, int MODE, int UNR, int NW>
+// Bias gathers take the SCALAR path where a wave holds few ratings (SPW <= 4, i.e. D >= 64): the ids come
+// out of the lanes by v_readlane and the 4-byte loads go through the scalar cache, so they do not queue
+// behind the row gathers in the vector memory pipeline.  Measured on the north-star shape
+// (tools/probes/fwd_shape.hip): per-group vector loads 45.6 us, scalar 42.9 us per 262144 ratings.  The
+// arrays are read-only for the whole launch (constant address space = s_load).  Narrow rows (SPW >= 8) use
+// one wave-wide vector load per table instead: lane j fetches the bias of the wave's j-th rating.
+typedef const float __attribute__((address_space(4))) * cfloat_p;
+
+template <int G, int VEC, int MODE, int UNR, int NW, bool PNT = false>
 __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nblocks) {
     constexpr int SPW = 64 / G;        // ratings per wave per pass; UNR passes in flight
+    constexpr bool SBIAS = SPW <= 4;
     constexpr int SPI = SPW * UNR;     // ratings per wave-iteration
     const int lane = threadIdx.x & 63;
     const int sub = lane / G;
@@ -221,10 +230,37 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
         float bu_[UNR], bi_[UNR];
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
-            p[j] = load_frag<VEC>(a.P + (size_t)u[j] * D, d0, D);
+            p[j] = load_frag<VEC, PNT>(a.P + (size_t)u[j] * D, d0, D);
             q[j] = load_frag<VEC>(a.Q + (size_t)it[j] * D, d0, D);
-            bu_[j] = a.bu[u[j]];
-            bi_[j] = a.bi[it[j]];
+        }
+        if constexpr (SBIAS) {
+            const cfloat_p cbu = (cfloat_p)(uintptr_t)a.bu;
+            const cfloat_p cbi = (cfloat_p)(uintptr_t)a.bi;
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                float xs[SPW], ys[SPW];
+#pragma unroll
+                for (int s2 = 0; s2 < SPW; ++s2) {
+                    xs[s2] = cbu[__builtin_amdgcn_readlane(u[j], s2 * G)];
+                    ys[s2] = cbi[__builtin_amdgcn_readlane(it[j], s2 * G)];
+                }
+                bu_[j] = xs[0]; bi_[j] = ys[0];
+#pragma unroll
+                for (int s2 = 1; s2 < SPW; ++s2) { if (sub == s2) { bu_[j] = xs[s2]; bi_[j] = ys[s2]; } }
+            }
+        } else {
+            // lane l = j * SPW + s holds rating (j, s) of this iteration (SPI <= 64 ratings): one load per table
+            int32_t mu_ = 0, mi_ = 0;
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                const int src = ((lane - j * SPW) & (SPW - 1)) * G;
+                const int32_t su = __shfl(u[j], src, 64), si = __shfl(it[j], src, 64);
+                if (lane / SPW == j) { mu_ = su; mi_ = si; }
+            }
+            float wx = 0.f, wy = 0.f;
+            if (lane < SPI) { wx = a.bu[mu_]; wy = a.bi[mi_]; }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) { bu_[j] = __shfl(wx, j * SPW + sub, 64); bi_[j] = __shfl(wy, j * SPW + sub, 64); }
         }
         if (base + stride < a.B) fetch_ids(base + stride);      // next iteration's ids, behind the rows
 #pragma unroll
@@ -280,9 +316,12 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
     if constexpr (MODE != MODE_INFER) block_sum_store<3, NW>(acc, a.partials + (size_t)block * 4);
 }
 
-template <int G, int VEC, int MODE, int UNR>
+// PNT: user rows by non-temporal loads - set when the user table cannot stay in the 256 MB Infinity Cache
+// anyway, so that it does not evict the item rows and the bias arrays, which can
+// (tools/probes/fwd_policy.hip: 48.3 -> 46.0 us per 262144 ratings at 10M x 1M rows)
+template <int G, int VEC, int MODE, int UNR, bool PNT>
 __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
-    forward_body<G, VEC, MODE, UNR, 4>(a, blockIdx.x, gridDim.x);
+    forward_body<G, VEC, MODE, UNR, 4, PNT>(a, blockIdx.x, gridDim.x);
 }
 
 // In-LDS exclusive scan of a tile's nb bin counts into the packed form (count << 16) | start.
@@ -1347,8 +1386,13 @@ __global__ void k_init_uniform_scalar(float* p, float lo, float hi, uint64_t see
 // launch helpers
 template <int MODE, int UNR>
 static void launch_forward_mode(const FwdArgs& a, int G, int VEC, int grid, hipStream_t s) {
+    const bool pnt = MODE != MODE_TRAIN && (size_t)a.U * a.D * 4 > ((size_t)256 << 20);
 #define TFR_FWD_CASE(g, v) \
-    if (G == g && VEC == v) { hipLaunchKernelGGL((k_forward<g, v, MODE, UNR>), dim3(grid), dim3(256), 0, s, a); return; }
+    if (G == g && VEC == v) {                                                                                  \
+        if (pnt) hipLaunchKernelGGL((k_forward<g, v, MODE, UNR, true>), dim3(grid), dim3(256), 0, s, a);       \
+        else hipLaunchKernelGGL((k_forward<g, v, MODE, UNR, false>), dim3(grid), dim3(256), 0, s, a);          \
+        return;                                                                                                \
+    }
     TFR_FWD_CASE(4, 4) TFR_FWD_CASE(8, 4) TFR_FWD_CASE(16, 4) TFR_FWD_CASE(32, 4) TFR_FWD_CASE(64, 4)
     TFR_FWD_CASE(4, 1) TFR_FWD_CASE(8, 1) TFR_FWD_CASE(16, 1) TFR_FWD_CASE(32, 1) TFR_FWD_CASE(64, 1)
 #undef TFR_FWD_CASE

@@ -172,6 +172,53 @@ class SvdModel:
                                                  L.ptr_f32(loss) if want_loss else None))
         return loss
 
+    # -- the ShuffleIterator id draw on the device (dataio.py:115; include/tfrecomm.h "id draw") -----
+    def rng_seed(self, seed):
+        """``np.random.seed(seed)`` for the device generator (svd_train_val.py:15)."""
+        L.check(self._lib.tfr_rng_seed(self._h, int(seed) & 0xFFFFFFFF))
+
+    def rng_set_state(self, key, pos):
+        k = np.ascontiguousarray(np.asarray(key, dtype=np.uint32)).reshape(-1)
+        if k.size != 624:
+            raise ValueError("MT19937 key must hold 624 words")
+        L.check(self._lib.tfr_rng_set_state(self._h, k.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos)))
+
+    def rng_get_state(self):
+        k, pos = np.empty(624, np.uint32), C.c_int32()
+        L.check(self._lib.tfr_rng_get_state(self._h, k.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos)))
+        return k, pos.value
+
+    def rng_from_numpy(self):
+        """Hand NumPy's legacy global generator (the one dataio.ShuffleIterator draws from) to the device."""
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            raise RuntimeError("NumPy's legacy generator is not MT19937")
+        self.rng_set_state(st[1], st[2])
+
+    def rng_to_numpy(self):
+        """...and back: host draws after this continue the stream where the device left it."""
+        k, pos = self.rng_get_state()
+        st = np.random.get_state()
+        np.random.set_state((st[0], k, pos, st[3], st[4]))
+
+    def draw_ids(self, high, count):
+        """``np.random.randint(0, high, (count,))`` drawn on the device (int64, bit-identical stream)."""
+        out = np.empty(int(count), np.int64)
+        L.check(self._lib.tfr_draw_ids(self._h, int(high), out.size, L.ptr_i64(out)))
+        return out
+
+    def train_steps_drawn(self, batch, nsteps, want_loss=False):
+        """nsteps x { next(iter_train); sess.run(train_op) } with the id draw, the gather from the resident
+        store and the step all on the device."""
+        loss = np.empty(nsteps, np.float32) if want_loss else None
+        L.check(self._lib.tfr_train_steps_drawn(self._h, int(batch), int(nsteps), L.ptr_f32(loss) if want_loss else None))
+        return loss
+
+    def train_step_ids(self, ids):
+        """One step on store rows ``ids`` (host int64, e.g. straight from np.random.randint); asynchronous."""
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.int64)).reshape(-1)
+        L.check(self._lib.tfr_train_step_ids(self._h, L.ptr_i64(a), a.size))
+
     def forward_resident(self, lo, hi):
         out = np.empty(hi - lo, np.float32)
         L.check(self._lib.tfr_forward_resident(self._h, lo, hi, L.ptr_f32(out)))
