@@ -278,7 +278,16 @@ enum {
     TFR_K_COUNT = 8
 };
 int tfr_profile(tfr_model* m, int32_t enable);                 /* enable resets the counters */
+/* "slot=kernel<template args>;..." - the kernels one training step of this model launches at this batch
+ * size, spelled as rocprofv3 prints them (what the slots above time) */
+int tfr_kernel_plan(tfr_model* m, int64_t batch, char* buf, int64_t buflen);
 int tfr_profile_read(tfr_model* m, int32_t kernel, double* total_ms, int64_t* launches);
+
+/* LDS budget guard: static + dynamic LDS bytes per workgroup that the dispatcher requests for a shape, computed
+ * on the host exactly as the launchers compute it (no device needed).  kernel: 0 k_tile_step, 1 k_seg_reduce with
+ * the forward inside, 2 k_front, 3 k_mt_draw, 4 k_seg_reduce.  A gfx950 CU has 160 KB. */
+int tfr_lds_bytes(int32_t kernel, int32_t dim, int64_t batch, int64_t user_num, int64_t item_num,
+                  int64_t* static_bytes, int64_t* dynamic_bytes);
 
 /* ---- misc ------------------------------------------------------------------------------ */
 int tfr_sync(tfr_model* m);            /* drains the stream; reports deferred TFR_ERR_OOB   */

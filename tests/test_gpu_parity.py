@@ -307,7 +307,7 @@ def test_frozen_tables_var_list():
 
 
 # ------------------------------------------------------------------ resident store / eval
-@pytest.mark.parametrize("case", range(13))
+@pytest.mark.parametrize("case", range(14))
 def test_lookahead_pipelines_equal_single_steps(case):
     """Multi-step calls sort the NEXT batch ahead of time (small tables: spare blocks of the current
     launch; big tables: a second stream).  Whatever the shapes, the optimiser and the way the steps are
@@ -318,14 +318,17 @@ def test_lookahead_pipelines_equal_single_steps(case):
     I = int(rs.randint(200, 20000)) if big else int(rs.choice([30, 500, 3952, 9000]))
     D = int(rs.choice([8, 20, 64, 128]))
     B = int(rs.choice([1, 63, 1000, 1024, 1025, 4097, 10000]))
-    if case >= 10:                                        # 13..16 tiles: the widest sweep variant; 17: past the tile path
-        U, I, D, B = 6040, 3952, [64, 128, 32][case - 10], [16384, 12289, 16385][case - 10]
+    if case >= 10:                                        # 13..16 tiles: the widest sweep variant; 17: past the tile path;
+        # case 13: the headline configuration (10 tiles: k_dense_tiles<16,4,false,10>)
+        U, I, D, B = 6040, 3952, [64, 128, 32, 64][case - 10], [16384, 12289, 16385, 10000][case - 10]
     N = 50000
     K = 7
     opt, mode = [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")][case % 3]
     if big and mode == "tf1" and opt == "adam":
         mode = "lazy"
     kw = dict(optimizer=opt, adam_mode=mode, loss=["mse", "nll"][case % 2], item_abs=bool(case & 2), reg_bias=bool(case & 4))
+    if case == 13:
+        kw = dict(optimizer="adam", adam_mode="tf1", loss="mse", item_abs=False, reg_bias=False)
     t = rand_tables(rs, U, I, D)
     su, si = dup_heavy_ids(rs, U, N), dup_heavy_ids(rs, I, N)
     sr = (rs.rand(N) < 0.5).astype(np.float32) if kw["loss"] == "nll" else rs.randint(1, 6, N).astype(np.float32)
@@ -440,6 +443,8 @@ def _sweep_cases():
     cases.append((104, 16384, 500, 128, 10000, "adam", "lazy", "nll", True, True))
     cases.append((105, 6040, 3952, 64, 16384, "adam", "tf1", "mse", False, True))
     cases.append((106, 9000, 16384, 256, 12289, "sgd", "tf1", "nll", True, False))
+    # the headline configuration itself (BASELINE configs[1]): k_tile_step<16,4,2> + k_dense_tiles<16,4,false,10>
+    cases.append((107, 6040, 3952, 64, 10000, "adam", "tf1", "mse", False, False))
     return cases
 
 

@@ -185,3 +185,46 @@ def test_fm_forward_matches_pairwise_sum_and_golden(golden):
             assert np.allclose(y, yref, rtol=1e-12, atol=1e-12)           # coincide on 0/1 features
         else:
             assert not np.allclose(y, yref, rtol=1e-3)                    # and differ on counts (SURVEY 8c ii)
+
+
+# the shapes of tests/test_gpu_parity.py::_sweep_cases where the GPU's Adam tables are held to 2e-4 instead of 1e-5
+_DRIFT_CASES = [
+    (107, 6040, 3952, 64, 10000, "adam", "tf1", "mse", False, False),      # the headline configuration
+    (104, 16384, 500, 128, 10000, "adam", "lazy", "nll", True, True),
+    (20, 1859, 1586, 60, 4097, "adam", "lazy", "nll", False, False),
+    (106, 9000, 16384, 256, 12289, "sgd", "tf1", "nll", True, False),
+    (2, 248, 203, 252, 1025, "sgd", "tf1", "mse", False, False),
+]
+
+
+def test_adam_table_drift_is_float32_arithmetic_not_the_kernels():
+    """north_star's 1e-5 is on loss / RMSE.  The GPU parity tests hold Adam-updated TABLES to 2e-4 (x a
+    run-length factor) and SGD tables to 4e-5.  This test shows that tolerance is the arithmetic's: the
+    oracle itself, run in float32 (sequential NumPy sums, no GPU, no kernels), drifts from its float64 self
+    by up to ~1.6e-4 on the same shapes under Adam - a handful of elements whose gradient nearly cancels,
+    where g / (sqrt(v) + eps) turns an fp32 rounding of g into a move of order lr - while logits and loss
+    stay at 1e-7 and SGD through the same code stays below 1e-6."""
+    worst = {}
+    for n, U, I, D, B, opt, mode, loss, item_abs, reg_bias in _DRIFT_CASES:
+        rs = np.random.RandomState(1000 + n)                   # the same draws as test_random_shapes_two_steps
+        t = rand_tables(rs, U, I, D, scale=0.3 / np.sqrt(max(D, 16) / 16))
+        kw = dict(loss=loss, item_abs=item_abs, reg_bias=reg_bias, optimizer=opt, adam_mode=mode, lr=3e-3, reg=0.02)
+        o64, o32 = make_oracle(U, I, D, t, **kw), make_oracle(U, I, D, t, dtype=np.float32, **kw)
+        for s in range(2):
+            u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+            r = (rs.rand(B) < 0.5).astype(np.float32) if loss == "nll" else rs.randint(1, 6, B).astype(np.float32)
+            l64, l32 = o64.train_step(u, i, r), o32.train_step(u, i, r)
+            assert rel_err(l32[0], l64[0]) <= 1e-5 and rel_err(l32[1], l64[1]) <= 1e-5          # logits, loss: the north-star bound holds
+        drift = max(rel_err(o32.tables()[tid], o64.tables()[tid]) for tid in o64.tables())
+        run = 7.0 * B / max(1, min(U, I))
+        tol = (2e-4 if opt == "adam" else 4e-5) * max(1.0, np.sqrt(run / 64))                   # what the GPU tests allow
+        assert drift <= tol, (n, drift, tol)
+        worst[opt] = max(worst.get(opt, 0.0), drift)
+        if n == 107:
+            # localise it: the worst element is one whose float64 update is far below the typical one (near-cancelling gradient)
+            d = np.abs(o32.P.astype(np.float64) - o64.P)
+            k = np.unravel_index(np.argmax(d), d.shape)
+            moved = np.abs(o64.P - t["P"].astype(np.float64))
+            assert moved[k] < 0.5 * np.median(moved[moved > 0])
+    assert worst["adam"] > 5e-5          # a pure float32 restatement cannot meet 1e-5 on Adam tables ...
+    assert worst["sgd"] < 2e-6           # ... while SGD through the same restatement is at rounding level

@@ -113,8 +113,10 @@ SIGNATURES = {
     "tfr_als_predict": (C.c_int, [_p, _i64p, _i64p, C.c_int64, _f64p]),
     "tfr_als_last_error": (C.c_char_p, []),
     "tfr_sort_segments": (C.c_int, [_p, C.c_int32, _i32p, C.c_int64, _i32p, _i32p]),
+    "tfr_kernel_plan": (C.c_int, [_p, C.c_int64, C.c_char_p, C.c_int64]),
     "tfr_profile": (C.c_int, [_p, C.c_int32]),
     "tfr_profile_read": (C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), _i64p]),
+    "tfr_lds_bytes": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _i64p, _i64p]),
     "tfr_sync": (C.c_int, [_p]),
     "tfr_last_error": (C.c_char_p, []),
     "tfr_version": (C.c_int, []),

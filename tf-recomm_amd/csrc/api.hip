@@ -1566,11 +1566,82 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
         const int64_t s0 = c == 0 ? 0 : ready.chunk0 + (int64_t)(c - 1) * ready.chunk;
         int64_t s1 = c == 0 ? ready.chunk0 : s0 + ready.chunk;
         if (s1 > nsteps) s1 = nsteps;
+        hipEvent_t pa = nullptr, pb = nullptr;
+        if (m->prof && hipEventCreate(&pa) == hipSuccess && hipEventCreate(&pb) == hipSuccess) (void)hipEventRecord(pa, m->stream3);
         if (rng != 0) launch_mt_draw(m->d_rng, m->d_ids + s0 * B, (s1 - s0) * B, rng, mask_for(rng), m->stream3);
+        if (pa && pb) { (void)hipEventRecord(pb, m->stream3); m->events.push_back({pa, pb, TFR_K_DRAW}); }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(m->chunk_ev[c], m->stream3));
     }
     return staged_steps(m, 0, B, nsteps, loss_out, &ready);
+}
+
+// which kernels (rocprof's demangled spelling of the template arguments) one training step of this model
+// launches at this batch size - so that bench.py can name what it timed and look the same kernels up in
+// the committed rocprofv3 summaries
+int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
+    MODEL_ENTER(m);
+    if (!buf || buflen < 64 || B < 1) return fail(TFR_ERR_ARG, "kernel_plan: need a buffer of >= 64 bytes and batch >= 1");
+    const tfr_opts& o = m->o;
+    const bool adam = o.optimizer == TFR_OPT_ADAM;
+    const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
+    const int G = m->G, V = m->VEC;
+    const bool small = (1 << (m->bits_u > m->bits_i ? m->bits_u : m->bits_i)) <= CSORT_MAX_BINS;
+    const bool csort = small && csort_eligible(B, m->bits_u, m->bits_i);
+    const int64_t ntiles = (B + CSORT_TILE - 1) / CSORT_TILE;
+    char tmp[1024];
+    if (csort && ntiles <= 16) {
+        const int nt = ntiles <= 4 ? 4 : ntiles <= 8 ? 8 : ntiles <= 10 ? 10 : ntiles <= 12 ? 12 : 16;
+        snprintf(tmp, sizeof(tmp), "reduce_item=k_tile_step<%d, %d, %d>;apply=k_dense_tiles<%d, %d, false, %d>", G, V,
+                 tile_step_epg((int)ntiles, G, V), G, V, nt);
+    } else if (!tf1 && !csort) {
+        const int rm = adam ? RMODE_ADAM : RMODE_SGD;
+        snprintf(tmp, sizeof(tmp), "gather=k_gather_triples;sort=k_rsort_rank/scan/scatter x%d passes;reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
+                 "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>;finalize=k_finalize",
+                 ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
+    } else if (csort) {
+        snprintf(tmp, sizeof(tmp), "forward=k_front<%d, %d>;sort=k_csort_scan/scatter;reduce_item=k_seg_reduce<%d, %d, %d, false, true>;apply=%s",
+                 G, V, G, V, tf1 ? RMODE_SCRATCH : (adam ? RMODE_ADAM : RMODE_SGD), tf1 ? "k_adam_dense" : "k_apply_rows");
+    } else {
+        snprintf(tmp, sizeof(tmp), "forward=k_forward<%d, %d, 1, 4, false>;sort=k_rsort_rank/scan/scatter;reduce_item=k_seg_reduce<%d, %d, 0, false, true>;apply=k_adam_dense<%d, %d>;finalize=k_finalize",
+                 G, V, G, V, G, V);
+    }
+    snprintf(buf, (size_t)buflen, "%s", tmp);
+    return TFR_OK;
+}
+
+// static + dynamic LDS bytes per workgroup of the shape-dependent kernels, computed exactly as the launchers do.
+// Needs no device (pure host arithmetic): tests/test_lds_budget.py enumerates every selectable combination.
+int tfr_lds_bytes(int32_t kernel, int32_t dim, int64_t batch, int64_t user_num, int64_t item_num,
+                  int64_t* static_bytes, int64_t* dynamic_bytes) {
+    int G, VEC;
+    if (!geometry(dim, &G, &VEC)) return fail(TFR_ERR_ARG, "unsupported dim %d", dim);
+    if (batch < 1 || user_num < 1 || item_num < 1) return fail(TFR_ERR_ARG, "lds_bytes: batch and row counts must be >= 1");
+    const int bu = bits_for(user_num), bi = bits_for(item_num);
+    const int nbmax = 1 << (bu > bi ? bu : bi);
+    int64_t st = 0, dy = 0;
+    if (kernel == 0 || kernel == 2) {                    // k_tile_step / k_front: small tables only
+        if (nbmax > CSORT_MAX_BINS || !csort_eligible(batch, bu, bi)) return fail(TFR_ERR_ARG, "shape does not take the counting-sort path");
+        const int64_t ntiles = (batch + CSORT_TILE - 1) / CSORT_TILE;
+        if (kernel == 0) {
+            if (ntiles > 16) return fail(TFR_ERR_ARG, "batch beyond 16 tiles does not take k_tile_step");
+            const int epg = tile_step_epg((int)ntiles, G, VEC);
+            st = (int64_t)tile_step_static_lds(G, epg);
+            dy = (int64_t)tile_step_dyn_lds(G, VEC, epg, nbmax);
+        } else {
+            st = 256 * 4 + 16 * 64 * 4 + 16 * 3 * 4;     // wtot, the forward's LDS-staged reduce slot, block_sum_store
+            dy = (int64_t)nbmax * 4;
+        }
+    } else if (kernel == 1 || kernel == 4) {             // k_seg_reduce with / without the forward inside
+        st = (int64_t)seg_reduce_static_lds(G, VEC, kernel == 1);
+    } else if (kernel == 3) {                            // k_mt_draw: two generator blocks + the wave counts
+        st = 2 * 624 * 4 + 2 * 10 * 4;
+    } else {
+        return fail(TFR_ERR_ARG, "lds_bytes: kernel must be 0 (k_tile_step), 1 (k_seg_reduce fwd), 2 (k_front), 3 (k_mt_draw), 4 (k_seg_reduce)");
+    }
+    if (static_bytes) *static_bytes = st;
+    if (dynamic_bytes) *dynamic_bytes = dy;
+    return TFR_OK;
 }
 
 static int ensure_ring(tfr_model* m, int64_t B) {

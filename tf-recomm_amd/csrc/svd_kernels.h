@@ -162,6 +162,22 @@ struct TileStepArgs {
     int32_t* next_tab[2]; int4* next_srt[2];
 };
 void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s);
+// LDS of k_tile_step<G, VEC, EPG>: the static arrays (the kernel static_asserts this sum against its own
+// declarations) and the dynamic request (sort bins first, then the wave-level ping-pong buffers).  A CU has 160 KB;
+// tfr_lds_bytes / tests/test_lds_budget.py enumerate every shape the dispatcher can select.
+constexpr size_t LDS_PER_CU = 160 * 1024;
+constexpr size_t tile_step_static_lds(int G, int EPG) {
+    return (size_t)5 * 1024 * 4                        /* rec_u, rec_i, rec_r, srt_key, srt_pos */
+           + (size_t)2 * EPG * 16 * 4 + (size_t)EPG * 16 * 4                 /* lds_gb, lds_key */
+           + (size_t)EPG * (2 * (1024 / G) + 1024) * 4                       /* lds_stage */
+           + 16 * 4;                                                         /* wtot */
+}
+constexpr size_t tile_step_dyn_lds(int G, int VEC, int EPG, int nbmax) {
+    return (size_t)nbmax * 4 > (size_t)2 * EPG * 16 * G * VEC * 4 ? (size_t)nbmax * 4 : (size_t)2 * EPG * 16 * G * VEC * 4;
+}
+constexpr size_t seg_reduce_static_lds(int G, int VEC, bool fwd) {
+    return (size_t)1024 * VEC * 4 + (size_t)2 * (1024 / G) * 4 + (fwd ? (size_t)(2 * (1024 / G) + 1024) * 4 + 16 * 3 * 4 : 4);
+}
 int tile_step_epg(int ntiles, int G, int VEC);       // pieces per block k_tile_step will use (grid = ntiles * G / epg per side)
 
 // row geometry for a dim: returns false if unsupported

@@ -169,26 +169,34 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
     const int gl = lane % G;
     const int d0 = gl * VEC;
     const int D = a.D;
-    const int64_t wave_id = (int64_t)block * NW + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)nblocks * NW * SPI;
+    // batch positions fit 32 bits (the workspace caps a batch at 2^30 ratings)
+    const int Bn = (int)a.B;
+    const int wave_id = block * NW + (threadIdx.x >> 6);
+    const int stride = nblocks * NW * SPI;
     const float mu = *a.mu;
 
     float acc[3] = {0.f, 0.f, 0.f};    // TRAIN: loss, reg, sum g | EVAL: sse, n_equal, -
     bool oob = false, oob_store = false;
 
-    // The ids of iteration n+1 are fetched while the rows of iteration n are in flight, so the
-    // only exposed memory round trip per iteration is the row gather itself.
+    // TRAIN (few, fat blocks: k_front, the sharded step): the ids of iteration n+1 are fetched while the rows
+    // of iteration n are in flight, so the only exposed round trip per iteration is the row gather itself.
+    // INFER / EVAL fetch them at the top of the iteration instead: without the second id set the kernel fits
+    // 64 VGPRs = 8 waves per SIMD, and the extra waves hide that round trip better than the prefetch did
+    // (north-star shape, one 262144-rating batch per launch: 51.0 -> 43.4 us together with the scalar-path
+    // bias loads and the non-temporal user rows; holding the kernel to 80 SGPRs for an eighth wave per SIMD
+    // changed nothing - gpurun_out/ns_s80_*.json; tools/probes/fwd_shape.hip).
+    constexpr bool PF = MODE == MODE_TRAIN;
     int32_t u_n[UNR], it_n[UNR];
     float rr_n[UNR];
-    auto fetch_ids = [&](int64_t base) {
+    auto fetch_ids = [&](int base) {
         if (a.ids) {
             // fused ShuffleIterator gather (dataio.py:115-117): id -> (user, item, rate) from the
             // HBM-resident store
             int64_t id[UNR];
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
-                const int64_t k = base + j * SPW + sub;
-                id[j] = (k < a.B) ? a.ids[k] : 0;
+                const int k = base + j * SPW + sub;
+                id[j] = (k < Bn) ? a.ids[k] : 0;
                 if ((uint64_t)id[j] >= (uint64_t)a.N) { oob_store = true; id[j] = 0; }
             }
 #pragma unroll
@@ -201,8 +209,8 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
         } else {
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
-                const int64_t k = base + j * SPW + sub;
-                const bool ok = k < a.B;
+                const int k = base + j * SPW + sub;
+                const bool ok = k < Bn;
                 u_n[j] = ok ? a.u[k] : 0;
                 it_n[j] = ok ? a.it[k] : 0;
                 rr_n[j] = (MODE != MODE_INFER && ok) ? a.r[k] : 0.f;
@@ -210,17 +218,18 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
         }
     };
 
-    int64_t base = wave_id * SPI;
-    if (base < a.B) fetch_ids(base);
-    for (; base < a.B; base += stride) {
-        int64_t k[UNR];
+    int base = wave_id * SPI;
+    if (PF && base < Bn) fetch_ids(base);
+    for (; base < Bn; base += stride) {
+        if (!PF) fetch_ids(base);
+        int k[UNR];
         int32_t u[UNR], it[UNR];
         bool ok[UNR];
         float rr[UNR];
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             k[j] = base + j * SPW + sub;
-            ok[j] = k[j] < a.B;
+            ok[j] = k[j] < Bn;
             u[j] = u_n[j]; it[j] = it_n[j]; rr[j] = rr_n[j];
             if (a.ids && a.u_out && gl == 0 && ok[j]) { a.u_out[k[j]] = u[j]; a.it_out[k[j]] = it[j]; }   // kept for the backward
             if ((uint64_t)(int64_t)u[j] >= (uint64_t)a.U) { oob = true; u[j] = 0; }
@@ -262,7 +271,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
 #pragma unroll
             for (int j = 0; j < UNR; ++j) { bu_[j] = __shfl(wx, j * SPW + sub, 64); bi_[j] = __shfl(wy, j * SPW + sub, 64); }
         }
-        if (base + stride < a.B) fetch_ids(base + stride);      // next iteration's ids, behind the rows
+        if (PF && base + stride < Bn) fetch_ids(base + stride);      // next iteration's ids, behind the rows
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             float s = 0.f, sq = 0.f;
@@ -323,7 +332,6 @@ template <int G, int VEC, int MODE, int UNR, bool PNT>
 __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
     forward_body<G, VEC, MODE, UNR, 4, PNT>(a, blockIdx.x, gridDim.x);
 }
-
 // In-LDS exclusive scan of a tile's nb bin counts into the packed form (count << 16) | start.
 // Thread t owns bins t, t + 1024, ... (bank-conflict free) and those bins are CONSECUTIVE in the
 // tile's sorted order (order index of bin q * 1024 + t is t * per + q): equal ids stay contiguous,
@@ -508,6 +516,9 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     __shared__ int32_t lds_key[EPG * 16];
     __shared__ float lds_stage[EPG * (2 * EPB + 1024)];
     __shared__ int32_t wtot[16];
+    static_assert(sizeof(rec_u) + sizeof(rec_i) + sizeof(srt_key) + sizeof(srt_pos) + sizeof(rec_r) + sizeof(lds_gb) + sizeof(lds_key) +
+                  sizeof(lds_stage) + sizeof(wtot) == tile_step_static_lds(G, EPG), "tile_step_static_lds() is out of date");
+    static_assert(tile_step_static_lds(G, EPG) + 64 * 1024 <= LDS_PER_CU, "static LDS leaves no room for 16384 sort bins");
     const int tid = threadIdx.x;
     const bool ahead = (int)blockIdx.x < nsort;          // look-ahead block: sort (side, tile) of the next batch
     if (ahead && blockIdx.y) return;
@@ -803,6 +814,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     __shared__ float lds_gb[EPB];
     __shared__ int32_t lds_key[EPB];
     __shared__ float lds_stage[FWD ? 2 * EPB + 1024 : 1];
+    static_assert(sizeof(lds_t) + sizeof(lds_gb) + sizeof(lds_key) + sizeof(lds_stage) + (FWD ? 16 * 3 * 4 : 0) == seg_reduce_static_lds(G, VEC, FWD),
+                  "seg_reduce_static_lds() is out of date");
     const RedArgs& a = pr.a[blockIdx.y];
     const int32_t err = *a.err;
     const int grp = threadIdx.x / G;
@@ -1438,7 +1451,9 @@ int tile_step_epg(int ntiles, int G, int VEC) {
     // smallest EPG in {1, 2, 4} that brings the grid (two sides) down to one block per CU (256 CUs), as far
     // as LDS allows: the wave-level ping-pong buffers (2 * EPG * 16 * G * VEC floats) share the 64 KB dynamic
     // region with the sort's bins; static arrays take another ~40 KB of the CU's 160 KB
-    auto fits = [&](int e) { return (size_t)2 * e * 16 * G * VEC * 4 <= (size_t)64 * 1024; };
+    auto fits = [&](int e) {
+        return (size_t)2 * e * 16 * G * VEC * 4 <= (size_t)64 * 1024 && tile_step_static_lds(G, e) + (size_t)64 * 1024 <= LDS_PER_CU;
+    };
     static int forced = -1;                              // TFR_EPG=1|2|4: A/B override
     if (forced < 0) { const char* e = getenv("TFR_EPG"); forced = e ? atoi(e) : 0; }
     if (forced == 1 || ((forced == 2 || forced == 4) && forced <= G && fits(forced))) return forced;
@@ -1452,6 +1467,7 @@ void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s) {
     const int epg = tile_step_epg(a.ntiles, G, VEC);
     size_t dyn = (size_t)nbmax * 4;                       // bins during the sort, contributions afterwards
     if (dyn < (size_t)2 * epg * 16 * G * VEC * 4) dyn = (size_t)2 * epg * 16 * G * VEC * 4;   // wave-level ping-pong buffers of the reduce
+    if (tile_step_static_lds(G, epg) + dyn > LDS_PER_CU) return;  // cannot happen for a shape tile_step_epg() admits (tests/test_lds_budget.py)
     const int nsort = a.next_ids ? 2 * a.next_ntiles : 0;         // look-ahead sort blocks come first
     const dim3 grid(nsort + a.ntiles * (G / epg), 2);
 #define TFR_TS_LAUNCH(g, v, e)                                                                        \

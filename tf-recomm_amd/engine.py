@@ -292,6 +292,12 @@ class SvdModel:
     def profile(self, enable=True):
         L.check(self._lib.tfr_profile(self._h, int(bool(enable))))
 
+    def kernel_plan(self, batch):
+        """{slot: kernel symbol} of one training step at this batch size (rocprofv3's spelling)."""
+        buf = C.create_string_buffer(1024)
+        L.check(self._lib.tfr_kernel_plan(self._h, int(batch), buf, 1024))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";") if kv)
+
     def profile_read(self):
         out = {}
         for k, name in enumerate(L.KERNEL_NAMES):
