@@ -129,8 +129,45 @@ def cpu_convergence(wl, train, val, tabs0, steps):
     from oracle import c_oracle
     U, I, D, B = wl["U"], wl["I"], wl["D"], wl["B"]
     orc = c_oracle.COracle(U, I, D, adam_mode=wl["adam_mode"], lr=wl["lr"], reg=wl["reg"])
-    orc.set_tables(*tabs0)
     tu, ti, tr = train
+    # how many threads: a GPU box exposes every host cpu (256) but gives this job a share of them, and an OpenMP
+    # team larger than the share crawls.  Take the cgroup quota if there is one; otherwise time each candidate
+    # team size (after ~1 s of warm-up: the first second after a team-size change is far slower) and keep the fastest.
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for qf, pf in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if pf is None:
+                q, per = open(qf).read().split()[:2]
+            else:
+                q, per = open(qf).read().strip(), open(pf).read().strip()
+            if q not in ("max", "-1"):
+                quota = max(1, int(math.ceil(float(q) / float(per))))
+                break
+        except (OSError, ValueError):
+            pass
+    cands = [min(quota, ncpu)] if quota else sorted({c for c in (4, 8, 16, 32, 64) if c <= ncpu} or {ncpu})
+    rs = np.random.RandomState(0)
+    best, tried = None, {}
+    for c in cands:
+        c_oracle.set_threads(c)
+        orc.set_tables(*tabs0)
+        t, t_start = [], time.perf_counter()
+        while True:
+            sel = rs.randint(0, len(tu), (B,))
+            bu, bi, br = tu[sel], ti[sel], tr[sel]
+            t0 = time.perf_counter()
+            orc.train_step(bu, bi, br, want_logits=False)
+            t.append(time.perf_counter() - t0)
+            if len(cands) == 1 or (len(t) >= 6 and time.perf_counter() - t_start > 1.5) or len(t) >= 400:
+                break
+        tried[c] = min(t[-3:])
+        if best is None or tried[c] < tried[best]:
+            best = c
+    c_oracle.set_threads(best)
+    orc.close()
+    orc = c_oracle.COracle(U, I, D, adam_mode=wl["adam_mode"], lr=wl["lr"], reg=wl["reg"])   # fresh optimiser state
+    orc.set_tables(*tabs0)
     np.random.seed(13575)                                       # svd_train_val.py:15
     cpu_s, done = 0.0, 0
     for s in range(steps):
@@ -142,12 +179,12 @@ def cpu_convergence(wl, train, val, tabs0, steps):
         done += 1
     vu, vi, vr = val
     rmse = float(np.sqrt(np.mean((orc.forward(vu, vi).astype(np.float64) - vr) ** 2)))
-    cores = c_oracle.threads()
     orc.close()
-    return rmse, dict(value=done * B / cpu_s, unit="ratings/s", cores=cores, kind="port",
+    return rmse, dict(value=done * B / cpu_s, unit="ratings/s", cores=best, kind="port",
                       sample="%d steps of the same workload (same initial tables, same id stream) in %.1f s of step time; "
                              "oracle/svd_oracle.c, OpenMP restatement of the svd_train_val.py step (TensorFlow unavailable); "
-                             "host has %d cpus" % (done, cpu_s, os.cpu_count()))
+                             "%d threads = the fastest team size on this host (ms per step by team size: %s; host exposes %d cpus)"
+                             % (done, cpu_s, best, ", ".join("%d: %.2f" % (c, v * 1e3) for c, v in sorted(tried.items())), ncpu))
 
 
 def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, D=128, B=262144, sequential=False, zipf=0.0):

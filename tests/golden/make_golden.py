@@ -227,7 +227,47 @@ def part6():
     np.savez_compressed(os.path.join(HERE, "als_trajectory.npz"), **out)
 
 
+def part7():
+    """CSV loaders pinned by the REAL reference readers (dataio.py:8-16,38-54): a small prepared-dataset folder
+    (data written here - synthetic rows, not reference content) is read with the reference's own
+    build_paths / read_process / get_data; the frames it returns are the fixture."""
+    sys.path.insert(0, "/root/reference")
+    import dataio as ref_dataio
+    root = os.path.join(HERE, "csv_fixture")
+    folder = os.path.join(root, "data", "tiny")
+    os.makedirs(folder, exist_ok=True)
+    rs = np.random.RandomState(99)
+    for name, n in (("train", 23), ("val", 7), ("test", 5)):
+        with open(os.path.join(folder, name + ".csv"), "w") as f:
+            for _ in range(n):
+                f.write("%d,%d,%d,%d,%d\n" % (rs.randint(0, 40), rs.randint(0, 30), rs.randint(0, 2), rs.randint(0, 6), rs.randint(0, 6)))
+    with open(os.path.join(folder, "tabbed.tsv"), "w") as f:        # read_process's default separator is a tab
+        for _ in range(4):
+            f.write("%d\t%d\t%.1f\t0\t0\n" % (rs.randint(0, 40), rs.randint(0, 30), rs.randint(1, 6)))
+    with open(os.path.join(folder, "config.yml"), "w") as f:
+        f.write("USER_NUM: 40\nITEM_NUM: 30\nNB_CLASSES: 2\nBATCH_SIZE: 8\n")
+    out = {}
+    cwd = os.getcwd()
+    os.chdir(root)                                                  # the reference's paths are relative: data/<name>/...
+    try:
+        paths = ref_dataio.build_paths("tiny")
+        out["paths"] = np.array([p.replace(os.sep, "/") for p in paths])
+        frames = dict(zip(("train", "val", "test"), ref_dataio.get_data("tiny")))
+        frames["tabbed"] = ref_dataio.read_process(os.path.join("data", "tiny", "tabbed.tsv"))
+    finally:
+        os.chdir(cwd)
+    for name, df in frames.items():
+        out[name + "/columns"] = np.array(list(df.columns))
+        for c in df.columns:
+            out["%s/%s" % (name, c)] = df[c].to_numpy()
+            out["%s/%s/dtype" % (name, c)] = np.array(str(df[c].dtype))
+    np.savez_compressed(os.path.join(HERE, "csv_frames.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "part7":
+        part7()
+        sys.exit(0)
     part1()
     part2()
     part3()
@@ -235,6 +275,7 @@ if __name__ == "__main__":
     if os.path.isdir("/root/reference"):
         part4()
         part6()
+        part7()
     else:
         print("note: /root/reference absent - iter_streams.npz not regenerated")
     for f in sorted(os.listdir(HERE)):

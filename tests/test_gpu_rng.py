@@ -138,3 +138,51 @@ def test_host_ids_async_steps_equal_resident_steps():
         m.train_step_ids(np.array([0, N], dtype=np.int64))       # out-of-range store index: reported at the next sync
         with pytest.raises(IndexError):
             m.sync()
+
+
+def test_run_ahead_between_calls_is_invisible():
+    """After a drawn call the generator keeps going into an alternate buffer for the NEXT call; a call with another
+    batch size or length, a host-visible draw, a state read or a new store in between must all see the stream exactly
+    where the consumed ids end."""
+    U, I, D, N = 300, 200, 16, 20000
+    rs = np.random.RandomState(8)
+    su, si = rs.randint(0, U, N).astype(np.int32), rs.randint(0, I, N).astype(np.int32)
+    sr = rs.randint(1, 6, N).astype(np.float32)
+    N2 = 7777
+    plan = [("steps", 1000, 3), ("steps", 1000, 5), ("steps", 1000, 1), ("steps", 700, 4), ("draw", 12345, 50), ("steps", 700, 9),
+            ("state",), ("steps", 700, 2), ("store", N2), ("steps", 256, 40), ("steps", 256, 40), ("steps", 256, 300)]
+    out = []
+    for device_draw in (False, True):
+        with T.SvdModel(U, I, D, adam_mode="lazy", device=0) as m:
+            m.init_tables(seed=2)
+            m.upload_triples(su, si, sr)
+            n_store = N
+            np.random.seed(99)
+            if device_draw:
+                m.rng_from_numpy()
+            log = []
+            for op in plan:
+                if op[0] == "steps":
+                    _, B, k = op
+                    if device_draw:
+                        log.append(m.train_steps_drawn(B, k, want_loss=True).tobytes())
+                    else:
+                        log.append(m.train_steps_resident(np.random.randint(0, n_store, (k, B)), B).tobytes())
+                elif op[0] == "draw":
+                    log.append((m.draw_ids(op[1], op[2]) if device_draw else np.random.randint(0, op[1], op[2])).tobytes())
+                elif op[0] == "state":
+                    if device_draw:
+                        key, pos = m.rng_get_state()
+                    else:
+                        st = np.random.get_state()
+                        key, pos = st[1], st[2]
+                    log.append((key.tobytes(), int(pos)))
+                else:
+                    n_store = op[1]
+                    m.upload_triples(su[:n_store], si[:n_store], sr[:n_store])
+            if device_draw:
+                m.rng_to_numpy()
+            log.append(np.random.randint(0, 1 << 30, 4).tobytes())
+            out.append((_digest(m), log))
+    assert out[0][0] == out[1][0]
+    assert out[0][1] == out[1][1]

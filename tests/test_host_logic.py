@@ -71,3 +71,25 @@ def test_sigmoid_helper():
 def test_run_without_model_or_init_is_an_error():
     with pytest.raises(RuntimeError):
         tf.Session().run(tf.global_variables_initializer())
+
+
+def test_csv_loaders_match_the_reference_readers_frames(golden):
+    """f3 pinned: tests/golden/csv_frames.npz holds the frames the REAL /root/reference/dataio.py
+    (build_paths / get_data / read_process) returned for the files under tests/golden/csv_fixture/
+    (make_golden.py part 7); the product's loaders must return the same columns, dtypes and values."""
+    import os
+    from tfrecomm_amd import dataio
+    g = golden("csv_frames.npz")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "csv_fixture")
+    got_paths = dataio.build_paths("tiny")
+    assert [p.replace(os.sep, "/") for p in got_paths] == list(g["paths"])
+    tr, va, te = dataio.get_data("tiny", data_folder=os.path.join(root, "data"))
+    frames = {"train": tr, "val": va, "test": te,
+              "tabbed": dataio.read_process(os.path.join(root, "data", "tiny", "tabbed.tsv"))}
+    for name, df in frames.items():
+        assert list(df.columns) == list(g[name + "/columns"])
+        for c in df.columns:
+            assert str(df[c].dtype) == str(g["%s/%s/dtype" % (name, c)]), (name, c)
+            assert np.array_equal(df[c].to_numpy(), g["%s/%s" % (name, c)], equal_nan=True), (name, c)
+    cfg = dataio.get_config(os.path.join(root, "data", "tiny", "config.yml"))
+    assert cfg == {"USER_NUM": 40, "ITEM_NUM": 30, "NB_CLASSES": 2, "BATCH_SIZE": 8}

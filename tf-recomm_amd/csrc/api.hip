@@ -94,6 +94,13 @@ struct tfr_model {
     // of the steps that consume them; one event per drawn chunk
     uint32_t* d_rng = nullptr;
     bool rng_set = false;
+    // run-ahead between calls: after a drawn call the generator goes on into the alternate id buffer, so the next
+    // call with the same batch size starts on ids that are already there; anything else that looks at the generator
+    // first puts it back to the snapshot taken where the consumed ids end
+    int64_t* d_ids_alt = nullptr; int64_t d_ids_alt_cap = 0;
+    uint32_t* d_rng_snap = nullptr;
+    bool spec_valid = false; int64_t spec_B = 0, spec_N = 0, spec_steps = 0;
+    hipEvent_t spec_ev = nullptr;
     hipStream_t stream3 = nullptr;
     std::vector<hipEvent_t> chunk_ev;
     hipEvent_t ev_ids_free = nullptr;
@@ -251,6 +258,8 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
     return TFR_OK;
 }
 
+static int cancel_run_ahead(tfr_model* m);
+
 static int ensure_step_out(tfr_model* m, int64_t nsteps) {
     if (nsteps <= m->step_out_cap) return TFR_OK;
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -322,7 +331,8 @@ int tfr_destroy(tfr_model* m) {
     if (m->stream3) { (void)hipStreamSynchronize(m->stream3); (void)hipStreamDestroy(m->stream3); }
     for (auto e : m->chunk_ev) (void)hipEventDestroy(e);
     if (m->ev_ids_free) (void)hipEventDestroy(m->ev_ids_free);
-    dfree(m->d_rng); dfree(m->d_ring);
+    dfree(m->d_rng); dfree(m->d_ring); dfree(m->d_ids_alt); dfree(m->d_rng_snap);
+    if (m->spec_ev) (void)hipEventDestroy(m->spec_ev);
     if (m->h_ring) (void)hipHostFree(m->h_ring);
     for (int z = 0; z < tfr_model::HRING; ++z) if (m->ring_ev[z]) (void)hipEventDestroy(m->ring_ev[z]);
     for (int z = 0; z < 2; ++z) { if (m->ev_sorted[z]) (void)hipEventDestroy(m->ev_sorted[z]); if (m->ev_free[z]) (void)hipEventDestroy(m->ev_free[z]); }
@@ -1198,6 +1208,7 @@ int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float
 // pack three columns (host or device) into the 16-byte-record store, in chunks
 static int build_store(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t N, bool on_device) {
     HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->spec_valid) { int rc0 = cancel_run_ahead(m); if (rc0) return rc0; }     // ids drawn ahead were for the old store size
     dfree(m->store);
     m->store = nullptr; m->N = 0; m->pf_valid = false;
     int rc;
@@ -1265,6 +1276,7 @@ int tfr_init_tables(tfr_model* m, uint64_t seed, float fstd, float bstd) {
     return TFR_OK;
 }
 
+static const int64_t IDS_MIN_CAP = (int64_t)1 << 24;   // 128 MB: a 900-step call at batch 10000 fits without reallocating
 // room for n staged ids (contents undefined afterwards); the stream must be idle
 static int ensure_ids(tfr_model* m, int64_t n) {
     m->n_ids = 0; m->pf_valid = false;
@@ -1273,8 +1285,9 @@ static int ensure_ids(tfr_model* m, int64_t n) {
         dfree(m->d_ids);
         m->d_ids = nullptr; m->d_ids_cap = 0;
         int rc;
-        if ((rc = dmalloc(&m->d_ids, (size_t)n))) return rc;
-        m->d_ids_cap = n;
+        const int64_t want = n < IDS_MIN_CAP ? IDS_MIN_CAP : n;      // allocations are slow: never size for a short call only
+        if ((rc = dmalloc(&m->d_ids, (size_t)want))) return rc;
+        m->d_ids_cap = want;
     }
     return TFR_OK;
 }
@@ -1335,17 +1348,76 @@ static int ensure_lookahead(tfr_model* m) {
 // Big tables, touched-rows optimiser: gather + radix sort (+ id range check) of batch s+1 do not depend
 // on the tables, are a few small latency-bound launches, and would otherwise head every step; they run
 // on a second stream into the alternate buffer set while step s's HBM-bound kernels own the CUs.
-// Steps whose ids are still being drawn on the side stream (tfr_train_steps_drawn): need(step, stream) makes
-// `stream` wait for the chunk that holds that step's ids.  NULL when the ids were staged by the host.
+// mask of legacy randint's rejection loop: smallest 2^k - 1 >= rng
+static uint32_t mask_for(uint32_t rng) {
+    uint32_t mk = rng;
+    mk |= mk >> 1; mk |= mk >> 2; mk |= mk >> 4; mk |= mk >> 8; mk |= mk >> 16;
+    return mk;
+}
+
+// Steps whose ids are drawn on the side stream (tfr_train_steps_drawn).  The draws are cut into chunks of whole steps -
+// small ones first, so the first steps start after two batches' worth of draws, then doubling while the generator's
+// lead over the steps allows it - and a chunk is ENQUEUED only when the step loop comes within `ahead` steps of it:
+// the host never spends a long stretch feeding the draw stream while the main stream sits empty.
+// need(step, stream) makes `stream` wait for the chunk that holds that step's ids.  NULL = ids staged by the host.
 struct IdsReady {
-    tfr_model* m; int64_t chunk0, chunk; int nchunks;
+    tfr_model* m = nullptr;
+    int64_t B = 0, nsteps = 0;
+    uint32_t rng = 0;
+    std::vector<int64_t> first;                            // first[c] = first step of chunk c; first[nchunks] = nsteps
+    int enq = 0;                                           // chunks enqueued so far
     int waited[2] = {-1, -1};                              // highest chunk waited for: [0] main stream, [1] stream2
-    int chunk_of(int64_t step) const { return step < chunk0 ? 0 : 1 + (int)((step - chunk0) / chunk); }
+    int64_t ahead = 4, pre = 0;                            // pre: steps whose ids the previous call drew ahead (chunk 0, event spec_ev)
+    int chunk_of(int64_t step) const {
+        int c = 0;
+        while (c + 1 < (int)first.size() - 1 && first[c + 1] <= step) ++c;
+        return c;
+    }
+    void plan(int64_t cap_steps, int64_t pre_steps) {
+        first.clear();
+        pre = pre_steps;
+        int64_t s = 0, n = pre ? pre : (nsteps < 2 ? nsteps : 2), done = 0;
+        enq = pre ? 1 : 0;
+        while (s < nsteps) {
+            first.push_back(s);
+            s += n; done += n;
+            // next size: 1 while little has been drawn, then roughly half of what is already behind (the generator is at
+            // most ~1.5x faster than a small-table step, so its lead grows by about a third of a step per step)
+            n = done / 3;
+            if (n < 1) n = 1;
+            if (n > cap_steps) n = cap_steps;
+            if (s + n > nsteps) n = nsteps - s;
+        }
+        first.push_back(nsteps);
+        ahead = 2 * cap_steps + 2;
+    }
+    int enqueue_through(int64_t step) {                    // every chunk that starts at or before `step`
+        const int nch = (int)first.size() - 1;
+        while (enq < nch && first[enq] <= step) {
+            const int c = enq++;
+            while ((int)m->chunk_ev.size() <= c) {
+                hipEvent_t e;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(TFR_ERR_HIP, "hipEventCreate failed");
+                m->chunk_ev.push_back(e);
+            }
+            const int64_t s0 = first[c], s1 = first[c + 1];
+            hipEvent_t pa = nullptr, pb = nullptr;
+            if (m->prof && hipEventCreate(&pa) == hipSuccess && hipEventCreate(&pb) == hipSuccess) (void)hipEventRecord(pa, m->stream3);
+            if (rng != 0) launch_mt_draw(m->d_rng, m->d_ids + s0 * B, (s1 - s0) * B, rng, mask_for(rng), m->stream3);
+            if (pa && pb) { (void)hipEventRecord(pb, m->stream3); m->events.push_back({pa, pb, TFR_K_DRAW}); }
+            if (hipGetLastError() != hipSuccess || hipEventRecord(m->chunk_ev[c], m->stream3) != hipSuccess)
+                return fail(TFR_ERR_HIP, "draw launch failed");
+        }
+        return TFR_OK;
+    }
     int need(int64_t step, hipStream_t st, int which) {
-        int c = chunk_of(step);
-        if (c >= nchunks) c = nchunks - 1;
+        if (step >= nsteps) step = nsteps - 1;
+        int rc = enqueue_through(step + ahead);
+        if (rc) return rc;
+        const int c = chunk_of(step);
         if (c > waited[which]) {                           // chunks complete in order on the draw stream
-            if (hipStreamWaitEvent(st, m->chunk_ev[c], 0) != hipSuccess) return fail(TFR_ERR_HIP, "hipStreamWaitEvent failed");
+            if (hipStreamWaitEvent(st, (c == 0 && pre) ? m->spec_ev : m->chunk_ev[c], 0) != hipSuccess)
+                return fail(TFR_ERR_HIP, "hipStreamWaitEvent failed");
             waited[which] = c;
         }
         return TFR_OK;
@@ -1457,10 +1529,21 @@ static int ensure_rng(tfr_model* m) {
     if (!m->d_rng) {
         int rc;
         if ((rc = dmalloc(&m->d_rng, 625))) return rc;
+        if ((rc = dmalloc(&m->d_rng_snap, 625))) return rc;
     }
     if (!m->stream3) {
         HIPCHK(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&m->ev_ids_free, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&m->spec_ev, hipEventDisableTiming));
+    }
+    return TFR_OK;
+}
+
+// forget the ids drawn ahead for a call that is not coming: the generator returns to where the consumed ids end
+static int cancel_run_ahead(tfr_model* m) {
+    if (m->spec_valid) {
+        m->spec_valid = false;
+        HIPCHK(hipMemcpyAsync(m->d_rng, m->d_rng_snap, 625 * 4, hipMemcpyDeviceToDevice, m->stream3));
     }
     return TFR_OK;
 }
@@ -1470,6 +1553,7 @@ int tfr_rng_set_state(tfr_model* m, const uint32_t* key, int32_t pos) {
     if (!key || pos < 0 || pos > 624) return fail(TFR_ERR_ARG, "rng_set_state: need key[624] and pos in [0, 624]");
     int rc;
     if ((rc = ensure_rng(m))) return rc;
+    m->spec_valid = false;                                 // the new state replaces whatever was drawn ahead
     HIPCHK(hipStreamSynchronize(m->stream3));
     uint32_t h[625];
     memcpy(h, key, 624 * 4);
@@ -1490,19 +1574,14 @@ int tfr_rng_seed(tfr_model* m, uint32_t seed) {
 int tfr_rng_get_state(tfr_model* m, uint32_t* key, int32_t* pos) {
     MODEL_ENTER(m);
     if (!m->rng_set) return fail(TFR_ERR_STATE, "no generator state: call tfr_rng_seed / tfr_rng_set_state first");
+    int rc;
+    if ((rc = cancel_run_ahead(m))) return rc;
     HIPCHK(hipStreamSynchronize(m->stream3));
     uint32_t h[625];
     HIPCHK(hipMemcpy(h, m->d_rng, sizeof(h), hipMemcpyDeviceToHost));
     if (key) memcpy(key, h, 624 * 4);
     if (pos) *pos = (int32_t)h[624];
     return TFR_OK;
-}
-
-// mask of legacy randint's rejection loop: smallest 2^k - 1 >= rng
-static uint32_t mask_for(uint32_t rng) {
-    uint32_t mk = rng;
-    mk |= mk >> 1; mk |= mk >> 2; mk |= mk >> 4; mk |= mk >> 8; mk |= mk >> 16;
-    return mk;
 }
 
 static int check_high(int64_t high) {
@@ -1519,13 +1598,24 @@ int tfr_draw_ids(tfr_model* m, int64_t high, int64_t count, int64_t* ids_out) {
     if (!m->rng_set) return fail(TFR_ERR_STATE, "no generator state: call tfr_rng_seed / tfr_rng_set_state first");
     if (count == 0) return TFR_OK;
     if (high == 1) { memset(ids_out, 0, (size_t)count * 8); return TFR_OK; }    // rng == 0: no draw is consumed
+    if ((rc = cancel_run_ahead(m))) return rc;
     int64_t* d = nullptr;
     if ((rc = dmalloc(&d, (size_t)count))) return rc;
     const uint32_t rng = (uint32_t)(high - 1);
-    launch_mt_draw(m->d_rng, d, count, rng, mask_for(rng), m->stream3);
+    unsigned long long* dbg = nullptr;
+    if (getenv("TFR_RNG_DEBUG")) (void)hipMalloc((void**)&dbg, 16);           // diagnostic: in-kernel clock of the generator
+    launch_mt_draw(m->d_rng, d, count, rng, mask_for(rng), m->stream3, dbg);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ids_out, d, (size_t)count * 8, hipMemcpyDeviceToHost, m->stream3);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream3);
+    if (dbg && e == hipSuccess) {
+        unsigned long long h[2] = {0, 0};
+        (void)hipMemcpy(h, dbg, 16, hipMemcpyDeviceToHost);
+        fprintf(stderr, "k_mt_draw: %lld ids, %llu shader cycles, %.1f us, %.0f MHz, %.1f cycles per 624-word block (mask %u, rng %u)\n",
+                (long long)count, h[0], h[1] / 100.0, h[1] ? h[0] * 100.0 / h[1] : 0.0,
+                h[0] / ((double)count * ((double)mask_for(rng) + 1.0) / ((double)rng + 1.0) / 624.0), mask_for(rng), rng);
+    }
+    dfree(dbg);
     dfree(d);
     if (e != hipSuccess) return fail(TFR_ERR_HIP, "draw_ids: %s", hipGetErrorString(e));
     return TFR_OK;
@@ -1540,40 +1630,65 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
     int rc;
     if ((rc = check_high(m->N))) return rc;
     const int64_t total = B * (int64_t)nsteps;
-    if (total > m->d_ids_cap) {                            // (re)allocation: nothing may still read the old buffer
-        HIPCHK(hipStreamSynchronize(m->stream));
-        if ((rc = ensure_ids(m, total))) return rc;
+    const uint32_t rng = (uint32_t)(m->N - 1);
+    int64_t pre = 0;
+    if (m->spec_valid && m->spec_B == B && m->spec_N == m->N && nsteps >= m->spec_steps) {
+        // the previous call left the first spec_steps batches of this one in the alternate buffer
+        pre = m->spec_steps;
+        m->spec_valid = false;
+        std::swap(m->d_ids, m->d_ids_alt);
+        std::swap(m->d_ids_cap, m->d_ids_alt_cap);
+        if (total > m->d_ids_cap) {                        // grow, keeping the head (rare: a longer call than ever before)
+            HIPCHK(hipStreamSynchronize(m->stream3));
+            int64_t* bigger = nullptr;
+            if ((rc = dmalloc(&bigger, (size_t)total))) return rc;         // total > capacity >= IDS_MIN_CAP
+            HIPCHK(hipMemcpy(bigger, m->d_ids, (size_t)pre * B * 8, hipMemcpyDeviceToDevice));
+            dfree(m->d_ids);
+            m->d_ids = bigger; m->d_ids_cap = total;
+        }
+        HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));          // everything queued so far: the earlier calls' steps
+    } else {
+        if ((rc = cancel_run_ahead(m))) return rc;
+        if (total > m->d_ids_cap) {                        // (re)allocation: nothing may still read the old buffer
+            HIPCHK(hipStreamSynchronize(m->stream));
+            if ((rc = ensure_ids(m, total))) return rc;
+        }
+        // the draws overwrite the id buffer: they may start once every step already queued has read it
+        HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));
+        HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));
     }
     m->pf_valid = false;                                   // the buffer's contents change: no published look-ahead sort survives
     m->n_ids = total;
-    // the draws overwrite the id buffer: they may start once every step already queued has read it
-    HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));
-    HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));
-    // chunk 0 = the first two steps (a step's launch also sorts the batch after it), then ~128K ids per chunk
     IdsReady ready;
-    ready.m = m;
-    ready.chunk0 = nsteps < 2 ? nsteps : 2;
-    ready.chunk = B >= 131072 ? 1 : 131072 / B;
-    ready.nchunks = 1 + (int)((nsteps - ready.chunk0 + ready.chunk - 1) / ready.chunk);
-    while ((int)m->chunk_ev.size() < ready.nchunks) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        m->chunk_ev.push_back(e);
-    }
-    const uint32_t rng = (uint32_t)(m->N - 1);
-    if (rng == 0) HIPCHK(hipMemsetAsync(m->d_ids, 0, (size_t)total * 8, m->stream3));
-    for (int c = 0; c < ready.nchunks; ++c) {
-        const int64_t s0 = c == 0 ? 0 : ready.chunk0 + (int64_t)(c - 1) * ready.chunk;
-        int64_t s1 = c == 0 ? ready.chunk0 : s0 + ready.chunk;
-        if (s1 > nsteps) s1 = nsteps;
-        hipEvent_t pa = nullptr, pb = nullptr;
-        if (m->prof && hipEventCreate(&pa) == hipSuccess && hipEventCreate(&pb) == hipSuccess) (void)hipEventRecord(pa, m->stream3);
-        if (rng != 0) launch_mt_draw(m->d_rng, m->d_ids + s0 * B, (s1 - s0) * B, rng, mask_for(rng), m->stream3);
-        if (pa && pb) { (void)hipEventRecord(pb, m->stream3); m->events.push_back({pa, pb, TFR_K_DRAW}); }
+    ready.m = m; ready.B = B; ready.nsteps = nsteps; ready.rng = rng;
+    ready.plan(B >= 65536 ? 1 : (65536 / B < 16 ? 65536 / B : 16), pre);     // a chunk holds at most ~64K ids / 16 steps
+    if (rng == 0) HIPCHK(hipMemsetAsync(m->d_ids, 0, (size_t)total * 8, m->stream3));   // one-rating store: no draw consumed
+    if ((rc = staged_steps(m, 0, B, nsteps, loss_out, &ready))) return rc;
+    if ((rc = ready.enqueue_through(nsteps))) return rc;   // (every chunk is out by now; this is a no-op kept for clarity)
+    // run ahead: the next call's first batches, into the other buffer (last read by the call before this one)
+    if (rng != 0) {
+        int64_t spec = 131072 / B;
+        if (spec > 8) spec = 8;
+        if (spec > nsteps) spec = nsteps;
+        if (spec < 1) spec = 1;
+        if (spec * B > m->d_ids_alt_cap || m->d_ids_alt_cap < m->d_ids_cap) {   // keep both buffers the same size: a repeat of this call then fits
+            HIPCHK(hipStreamSynchronize(m->stream));       // the old alternate buffer may still be read by queued steps
+            HIPCHK(hipStreamSynchronize(m->stream3));
+            dfree(m->d_ids_alt);
+            m->d_ids_alt = nullptr; m->d_ids_alt_cap = 0;
+            int64_t want = spec * B > m->d_ids_cap ? spec * B : m->d_ids_cap;
+            if (want < IDS_MIN_CAP) want = IDS_MIN_CAP;
+            if ((rc = dmalloc(&m->d_ids_alt, (size_t)want))) return rc;
+            m->d_ids_alt_cap = want;
+        }
+        HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));  // the alternate buffer's last readers (before this call) are done
+        HIPCHK(hipMemcpyAsync(m->d_rng_snap, m->d_rng, 625 * 4, hipMemcpyDeviceToDevice, m->stream3));
+        launch_mt_draw(m->d_rng, m->d_ids_alt, spec * B, rng, mask_for(rng), m->stream3);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(m->chunk_ev[c], m->stream3));
+        HIPCHK(hipEventRecord(m->spec_ev, m->stream3));
+        m->spec_valid = true; m->spec_B = B; m->spec_N = m->N; m->spec_steps = spec;
     }
-    return staged_steps(m, 0, B, nsteps, loss_out, &ready);
+    return TFR_OK;
 }
 
 // which kernels (rocprof's demangled spelling of the template arguments) one training step of this model

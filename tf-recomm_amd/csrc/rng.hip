@@ -15,6 +15,16 @@
 // apply the rejection test and compact the accepted values in stream order (ballot ranks inside a
 // wave, a 10-entry wave-count table across waves).  The barrier that publishes the new block also
 // publishes the wave counts: one barrier per 624 draws.
+//
+// The generator is a single workgroup, so its speed is ONE CU's vector issue rate: measured (TFR_RNG_DEBUG=1,
+// in-kernel s_memtime at 2.4 GHz) ~1500 cycles per 624-word block = ~1 ns per draw, i.e. ~14 us for a
+// 10000-id batch of a 900188-rating store and ~400 us for 262144 ids of a 90M store - in both cases less than the
+// training step that consumes them, and the draws run on their own stream ahead of the steps.  In-kernel stamps
+// showed each wave spending ~10 cycles per instruction (ten waves share four SIMDs), so what counts is the
+// instruction total: the three forms of the regeneration (one, two or three tw terms) are dealt out per WAVE (scalar
+// branches on the wave index, all LDS reads of a form issued together, one LDS round trip per block), the two waves
+// that straddle a form boundary use masked variants, the block's last word (five tw terms) is computed on the
+// lightest SIMD, and block k's ranking / stores overlap block k+2's regeneration (software pipeline).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svd_kernels.h"
@@ -23,7 +33,7 @@ namespace tfr {
 
 __device__ __forceinline__ uint32_t mt_tw(uint32_t a, uint32_t b) {
     const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    return (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1u)) & 0x9908b0dfu);
 }
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
@@ -35,7 +45,8 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 }
 
 // word i of the block that follows block o (the in-place regeneration loop of genrand, unrolled so
-// that only old words appear on the right-hand side)
+// that only old words appear on the right-hand side).  Reference form; the kernel below evaluates the
+// same expressions with the case split made per wave.
 __device__ __forceinline__ uint32_t mt_next_word(const uint32_t* o, int i) {
     if (i < 227) return o[i + 397] ^ mt_tw(o[i], o[i + 1]);
     if (i < 454) return o[i + 170] ^ mt_tw(o[i - 227], o[i - 226]) ^ mt_tw(o[i], o[i + 1]);
@@ -51,49 +62,134 @@ __device__ __forceinline__ uint32_t mt_next_word(const uint32_t* o, int i) {
 // the loop ends for all threads at once (produced is computed identically by all of them).
 constexpr int MT_THREADS = 640;
 constexpr int MT_WAVES = MT_THREADS / 64;
+constexpr int MT_PAD = 648;                              // words per buffer: lanes 624..639 read (and ignore) the padding
 
 __global__ __launch_bounds__(MT_THREADS) void k_mt_draw(uint32_t* __restrict__ state, int64_t* __restrict__ out,
-                                                        int64_t need, uint32_t rng, uint32_t mask) {
-    __shared__ uint32_t st[2][624];
-    __shared__ int32_t cnt[2][MT_WAVES];
-    const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
+                                                        int32_t need, uint32_t rng, uint32_t mask, unsigned long long* __restrict__ dbg) {
+    const unsigned long long t_c0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull, t_r0 = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    __shared__ uint32_t st[2][MT_PAD];
+    __shared__ int32_t cnt[2][16];
+    const int i = threadIdx.x, lane = i & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
     const bool own = i < 624;
-    if (own) st[0][i] = state[i];
+    st[0][i] = own ? state[i] : 0u;
+    st[1][i] = 0u;
+    if (i < 8) { st[0][640 + i] = 0u; st[1][640 + i] = 0u; }
     int start = (int)state[624];
     __syncthreads();
-    int cur = 0, par = 0;
-    int64_t produced = 0;
-    while (produced < need) {
-        uint32_t w = 0, nxt = 0;
-        if (own) { w = st[cur][i]; nxt = mt_next_word(st[cur], i); }
-        const uint32_t val = mt_temper(w) & mask;
-        const bool acc = own && i >= start && val <= rng;
-        const unsigned long long bal = __ballot(acc);
-        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
-        if (own) st[cur ^ 1][i] = nxt;
-        if (lane == 0) cnt[par][wave] = __popcll(bal);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int q = 0; q < MT_WAVES; ++q) {
-            const int c = cnt[par][q];
-            if (q < wave) before += c;
-            total += c;
+    // per-lane constants of the masked forms: wave 3 holds words 192..255 (form 1 below 227, form 2 from 227),
+    // wave 7 holds 448..511 (form 2 below 454, form 3 from 454)
+    const int b3 = i < 227 ? i + 397 : i + 170;          // wave 3: base word
+    const int p3 = i < 227 ? 0 : i - 227;                //         second pair (masked off below 227)
+    const uint32_t m3 = i < 227 ? 0u : 0xffffffffu;
+    const int b7 = i < 454 ? i + 170 : i - 57;           // wave 7: base word
+    const int p7 = i < 454 ? 0 : i - 454;                //         third pair (masked off below 454)
+    const uint32_t m7 = i < 454 ? 0u : 0xffffffffu;
+    // word i of the block after block o (the forms dealt out per wave; see mt_next_word for the plain statement).
+    // Every form reads all its operands before it combines them: one LDS round trip per block.  The block's last
+    // word (two NEW words among its inputs: five tw terms) is computed by wave 2 - the lightest SIMD (waves 2 and 6) -
+    // and returned in `last`; its lane 0 stores it.
+    auto regen = [&](const uint32_t* o, uint32_t& w, uint32_t& last) -> uint32_t {
+        if (wave < 3) {                                                                        // words 0..191
+            const uint32_t a0 = o[i], a1 = o[i + 1], bs = o[i + 397];
+            w = a0;
+            if (wave == 2) {
+                const uint32_t x566 = o[566], x169 = o[169], x170 = o[170], x396 = o[396], x397 = o[397], x0 = o[0], x1 = o[1], x623 = o[623];
+                const uint32_t n396 = x566 ^ mt_tw(x169, x170) ^ mt_tw(x396, x397);
+                const uint32_t n0 = x397 ^ mt_tw(x0, x1);
+                last = n396 ^ mt_tw(x623, n0);
+            }
+            return bs ^ mt_tw(a0, a1);
         }
-        const int64_t off = produced + before + rank;
+        if (wave == 3) {                                                                       // 192..255
+            const uint32_t a0 = o[i], a1 = o[i + 1], bs = o[b3], c0 = o[p3], c1 = o[p3 + 1];
+            w = a0;
+            return bs ^ mt_tw(a0, a1) ^ (mt_tw(c0, c1) & m3);
+        }
+        if (wave < 7) {                                                                        // 256..447
+            const uint32_t a0 = o[i], a1 = o[i + 1], bs = o[i + 170], c0 = o[i - 227], c1 = o[i - 226];
+            w = a0;
+            return bs ^ mt_tw(a0, a1) ^ mt_tw(c0, c1);
+        }
+        if (wave == 7) {                                                                       // 448..511
+            const uint32_t a0 = o[i], a1 = o[i + 1], bs = o[b7], c0 = o[i - 227], c1 = o[i - 226], e0 = o[p7], e1 = o[p7 + 1];
+            w = a0;
+            return bs ^ mt_tw(a0, a1) ^ mt_tw(c0, c1) ^ (mt_tw(e0, e1) & m7);
+        }
+        const int c = own ? i : 623;                     // 512..623 (lanes 624..639 compute padding; word 623 comes from wave 2)
+        const uint32_t a0 = o[i], a1 = o[i + 1], bs = o[c - 57], c0 = o[c - 227], c1 = o[c - 226], e0 = o[c - 454], e1 = o[c - 453];
+        w = a0;
+        return bs ^ mt_tw(a0, a1) ^ mt_tw(c0, c1) ^ mt_tw(e0, e1);
+    };
+    // Software pipeline: while block `cur`'s accepted draws are ranked and stored, the block after the next is already
+    // being regenerated - the generator is a chain of dependent LDS round trips, and all ten waves walk it in step, so
+    // the only latency hiding there is comes from putting independent work side by side.
+    //   registers: val / acc / rank of block cur;   st[cur ^ 1]: block cur + 1;   cnt[cur]: block cur's wave counts
+    int cur = 0;
+    int32_t produced = 0;
+    uint32_t val;
+    bool acc;
+    int rank;
+    {
+        uint32_t w, last = 0;
+        const uint32_t nxt = regen(st[0], w, last);
+        val = mt_temper(w) & mask;
+        acc = own && i >= start && val <= rng;
+        const unsigned long long bal = __ballot(acc);
+        rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        __syncthreads();                                 // every wave has read its words of st[0] and st[1] is unused so far
+        if (i < 623) st[1][i] = nxt;
+        if (i == 128) st[1][623] = last;
+        if (lane == 0) cnt[0][wave] = __popcll(bal);
+        __syncthreads();
+    }
+    while (need > 0) {
+        // (1) block cur + 2 from block cur + 1
+        int c = lane < MT_WAVES ? cnt[cur][lane] : 0;    // block cur's wave counts: read in the same LDS round trip
+        uint32_t w2, last2 = 0;
+        const uint32_t nxt2 = regen(st[cur ^ 1], w2, last2);
+        // (2) block cur: prefix over the ten wave counts (lane q holds count q; inclusive scan by row shifts), then the ids
+        c += __builtin_amdgcn_update_dpp(0, c, 0x111, 0xf, 0xf, true);     // row_shr:1
+        c += __builtin_amdgcn_update_dpp(0, c, 0x112, 0xf, 0xf, true);     // row_shr:2
+        c += __builtin_amdgcn_update_dpp(0, c, 0x114, 0xf, 0xf, true);     // row_shr:4
+        c += __builtin_amdgcn_update_dpp(0, c, 0x118, 0xf, 0xf, true);     // row_shr:8
+        const int total = __builtin_amdgcn_readlane(c, MT_WAVES - 1);
+        const int before = wave ? __builtin_amdgcn_readlane(c, wave - 1) : 0;
+        const int32_t off = produced + before + rank;
         if (acc && off < need) {
             out[off] = (int64_t)val;
             if (off == need - 1) state[624] = (uint32_t)(i + 1);     // the draw after the last one consumed
         }
         produced += total;
-        if (produced >= need) break;                     // block `cur` is the state to keep
-        cur ^= 1; par ^= 1; start = 0;
+        if (produced >= need) break;                     // block `cur` (still intact in st[cur]) is the state to keep
+        // (3) block cur + 1 becomes the current one
+        val = mt_temper(w2) & mask;
+        acc = own && val <= rng;
+        const unsigned long long bal = __ballot(acc);
+        rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (i < 623) st[cur][i] = nxt2;
+        if (i == 128) st[cur][623] = last2;
+        if (lane == 0) cnt[cur ^ 1][wave] = __popcll(bal);
+        __syncthreads();
+        cur ^= 1;
     }
     if (need > 0 && own) state[i] = st[cur][i];
+    if (dbg && i == 0) {                                 // diagnostic only (TFR_RNG_DEBUG): shader cycles, 100 MHz ticks
+        dbg[0] = __builtin_amdgcn_s_memtime() - t_c0;
+        dbg[1] = __builtin_amdgcn_s_memrealtime() - t_r0;
+    }
 }
 
-void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rng, uint32_t mask, hipStream_t s) {
-    hipLaunchKernelGGL(k_mt_draw, dim3(1), dim3(MT_THREADS), 0, s, d_state, d_out, need, rng, mask);
+void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rng, uint32_t mask, hipStream_t s,
+                    unsigned long long* d_dbg) {
+    // one launch draws < 2^31 ids (32-bit offsets inside the kernel); larger requests are cut here - the
+    // state carries over from launch to launch on the stream
+    while (need > 0) {
+        const int64_t n = need < ((int64_t)1 << 30) ? need : ((int64_t)1 << 30);
+        hipLaunchKernelGGL(k_mt_draw, dim3(1), dim3(MT_THREADS), 0, s, d_state, d_out, (int32_t)n, rng, mask, d_dbg);
+        d_out += n;
+        need -= n;
+    }
 }
 
 }  // namespace tfr

@@ -208,7 +208,8 @@ void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, 
 void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s);
 
 // rng.hip: NumPy's legacy randint(0, rng + 1, (need,)) from the MT19937 state {key[624], pos} at d_state
-void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rng, uint32_t mask, hipStream_t s);
+void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rng, uint32_t mask, hipStream_t s,
+                    unsigned long long* d_dbg = nullptr);     // d_dbg: optional {shader cycles, 100 MHz ticks} of the launch
 
 // sort.hip
 constexpr int CSORT_TILE = 1024;

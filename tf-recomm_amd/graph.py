@@ -1,9 +1,14 @@
 """The sliver of the TensorFlow-1.x session API that svd_train_val.py drives the hot path
-through (svd_train_val.py:40-57,70-72,120-122,197-198), backed by the HIP library:
+through (svd_train_val.py:20-21,40-57,70-72,120-122,189-198), backed by the HIP library, under the
+names the reference spells (``from tfrecomm_amd import graph as tf``):
 
-    placeholder, get_or_create_global_step / get_global_step, global_variables_initializer,
-    local_variables_initializer, group, Session.run(fetches, feed_dict), Saver.save/restore,
-    reset_default_graph
+    tf.int32 / tf.float32, tf.placeholder, tf.train.get_or_create_global_step / get_global_step,
+    tf.global_variables_initializer, tf.local_variables_initializer, tf.local_variables, tf.group,
+    tf.Session().run(fetches, feed_dict) (+ .graph), tf.train.Saver().save/restore,
+    tf.summary.FileWriter(logdir, graph).add_summary(summary, step) with
+    summary_pb2.Summary(value=[summary_pb2.Summary.Value(tag=..., simple_value=...)])
+    (``from tfrecomm_amd.graph import summary_pb2`` for ``tensorflow.core.framework.summary_pb2``),
+    tf.reset_default_graph
 
 There is no graph compiler here: ``ops.inference_svd`` / ``ops.optimization`` record one model
 spec in the default graph, and ``Session.run`` maps the fetch list onto one C-ABI call:
@@ -13,10 +18,18 @@ pre-update logits like TF does for ``sess.run([train_op, logits, infer])``), oth
 """
 from __future__ import annotations
 
+import json
+import os
+import time
+import types
+
 import numpy as np
 
 from . import _lib as L
 from .engine import SvdModel
+
+# dtypes as the reference names them (svd_train_val.py:40-44)
+int32, int64, float32, float64 = np.dtype(np.int32), np.dtype(np.int64), np.dtype(np.float32), np.dtype(np.float64)
 
 
 class Handle(object):
@@ -77,6 +90,11 @@ def get_or_create_global_step():
     if _default.global_step is None:
         _default.global_step = Handle("global_step", "global_step", graph=_default)
     return _default.global_step
+
+
+def local_variables():
+    """tf.local_variables() (svd_train_val.py:17-18): this graph has none."""
+    return []
 
 
 def global_variables_initializer():
@@ -251,3 +269,50 @@ class Saver(object):
                 m.set_table(tid | L.SLOT_V, data[name + "/Adam_1"])
         m.set_step(int(data["global_step"]), float(data["beta1_power"]), float(data["beta2_power"]))
         sess.graph.initialized = True
+
+
+# ---- TensorBoard-free stand-ins for the summary calls of svd_train_val.py:20-21,57,189-192 -------------
+class _SummaryValue(object):
+    def __init__(self, tag=None, simple_value=None):
+        self.tag, self.simple_value = tag, simple_value
+
+
+class _Summary(object):
+    """summary_pb2.Summary(value=[summary_pb2.Summary.Value(tag=name, simple_value=val)])"""
+    Value = _SummaryValue
+
+    def __init__(self, value=()):
+        self.value = list(value)
+
+
+summary_pb2 = types.SimpleNamespace(Summary=_Summary)
+
+
+class FileWriter(object):
+    """tf.summary.FileWriter(logdir=..., graph=...): one JSON line per scalar in <logdir>/events.jsonl
+    ({"wall_time", "step", "tag", "simple_value"}) instead of a TensorBoard event file."""
+
+    def __init__(self, logdir, graph=None, **_):
+        self.logdir = logdir
+        os.makedirs(logdir, exist_ok=True)
+        self.path = os.path.join(logdir, "events.jsonl")
+        self._fh = open(self.path, "a")
+        if graph is not None and getattr(graph, "spec", None):
+            self._fh.write(json.dumps(dict(wall_time=time.time(), graph=dict(graph.spec))) + "\n")
+
+    def add_summary(self, summary, global_step=None):
+        for v in getattr(summary, "value", []):
+            self._fh.write(json.dumps(dict(wall_time=time.time(), step=None if global_step is None else int(global_step),
+                                           tag=v.tag, simple_value=None if v.simple_value is None else float(v.simple_value))) + "\n")
+        self._fh.flush()
+
+    def flush(self):
+        self._fh.flush()
+
+    def close(self):
+        self._fh.close()
+
+
+# the namespaces the reference reaches these through: tf.train.*, tf.summary.*
+train = types.SimpleNamespace(get_or_create_global_step=get_or_create_global_step, get_global_step=get_global_step, Saver=Saver)
+summary = types.SimpleNamespace(FileWriter=FileWriter, Summary=_Summary)

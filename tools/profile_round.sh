@@ -1,11 +1,27 @@
+# One gpurun call that produces every rocprofv3 artefact of a round (copied into profiles/ afterwards):
+#   bash tools/profile_round.sh r02 [only=<workload>]
+# Per workload: one --kernel-trace --stats pass (durations) and four separate --pmc passes (FETCH_SIZE; WRITE_SIZE;
+# TCC_HIT/MISS; TCC_EA0_RDREQ/WRREQ) - never combined with other trace domains (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -e
+R=${1:-r02}
+ONLY=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_r01b
+O=gpurun_out/prof_$R
 mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
-  N=$(echo $C | tr ' ' '_')
-  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$N -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline > $O/pmc_$N.log 2>&1
-  echo done $N
-done
+run() {   # name, bench args...
+  local name=$1; shift
+  if [ -n "$ONLY" ] && [ "$ONLY" != "$name" ]; then return; fi
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$name -- python3 bench.py "$@" > $O/bench_$name.json 2> $O/stats_$name.log || echo "stats $name failed"
+  for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+    N=$(echo $C | tr ' ' '_')
+    timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${name}_$N -- python3 bench.py "$@" > $O/pmc_${name}_$N.log 2>&1 || echo "pmc $name $N failed"
+    echo done $name $N
+  done
+}
+run c2 --steps 200 --warmup 20 --no-cpu-baseline --no-north-star --no-convergence
+run forward_uniform --only-north-star --steps 100 --warmup 10
+run forward_zipf --only-north-star --steps 100 --warmup 10 --ns-zipf 1.05
+run forward_8x_batch --only-north-star --steps 30 --warmup 4 --ns-batch 2097152
+run c3 --workload c3 --steps 40 --warmup 8 --no-cpu-baseline --no-north-star
+run c5 --workload c5 --steps 30 --warmup 5 --no-cpu-baseline
 ls $O

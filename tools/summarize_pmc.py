@@ -1,25 +1,22 @@
 #!/usr/bin/env python3
-"""Reduce rocprofv3 --pmc passes (one directory per pass, each holding *_counter_collection.csv) to
-profiles/rNN_pmc_summary.csv: per kernel and counter, the per-dispatch mean / min / max.
+"""Reduce the rocprofv3 --pmc passes of ONE workload (one directory per pass, each holding *_counter_collection.csv)
+to profiles/rNN_pmc_<workload>.csv: per kernel and counter, the per-dispatch mean / min / max.
 
-    python tools/summarize_pmc.py gpurun_out/prof_r01/pmc_* > profiles/r01_pmc_summary.csv
+    python tools/summarize_pmc.py gpurun_out/prof_r02/pmc_c3_* > profiles/r02_pmc_c3.csv
 
-bench.py launches the dim-128 forward (k_forward<32, 4, 0, 4>) in three groups - 110 launches with
-uniform ids, 110 with Zipf(1.05) item ids, 34 on eight batches at once - so that kernel's dispatches
-are also reported per group, in dispatch order ("[uniform]" / "[zipf]" / "[8x_batch]"), next to the
-combined row.  Older runs without the third group (220 dispatches) split in two."""
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16-byte-per-lane read,
+so read bytes = TCC_EA0_RDREQ x 128 B (MI355X_MICROARCH.md, "HBM")."""
 import csv
 import glob
 import re
 import sys
 from collections import defaultdict
 
-SPLIT = "k_forward<32, 4, 0, 4>"
-
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    return re.sub(r"\(.*$", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return re.sub(r"^tfr::", "", name)
 
 
 def main(dirs):
@@ -30,18 +27,9 @@ def main(dirs):
                 rows[(short(r["Kernel_Name"]), r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     out = csv.writer(sys.stdout)
     out.writerow(["kernel", "counter", "dispatches", "mean", "min", "max"])
-
-    def emit(k, c, vals):
-        out.writerow([k, c, len(vals), "%.6g" % (sum(vals) / len(vals)), "%.6g" % min(vals), "%.6g" % max(vals)])
     for (k, c) in sorted(rows):
         seq = [v for _, v in sorted(rows[(k, c)])]
-        emit(k, c, seq)
-        if SPLIT in k:
-            groups = {254: (("uniform", 110), ("zipf", 110), ("8x_batch", 34)), 220: (("uniform", 110), ("zipf", 110))}.get(len(seq), ())
-            lo = 0
-            for name, cnt in groups:
-                emit(k + " [%s]" % name, c, seq[lo:lo + cnt])
-                lo += cnt
+        out.writerow([k, c, len(seq), "%.6g" % (sum(seq) / len(seq)), "%.6g" % min(seq), "%.6g" % max(seq)])
 
 
 if __name__ == "__main__":
