@@ -885,6 +885,10 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
         r.item_abs = o.item_abs; r.reg_bias = o.reg_bias;
         r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
+        // big tables: every row of this step is touched once and cannot stay cached - non-temporal loads / stores for the
+        // rows, default policy only for reading back the pre-update copies (A/B in one gpurun call, TFR_NT=<bits>:
+        // 523-548 us/step with 0, 498 with 23; bits in svd_kernels.h RedArgs::nt)
+        { static int nt = -1; if (nt < 0) { const char* e = getenv("TFR_NT"); nt = e ? atoi(e) : 23; } r.nt = fwd_fused ? nt : 0; }
         // item side -> scratch (reads the pre-update user rows)
         RedArgs ri = r;
         ri.side = 1;

@@ -50,6 +50,8 @@ struct RedArgs {
     int64_t B;
     int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;
     int32_t tile;                                  // >0: the sorted order restarts every `tile` entries
+    int32_t nt;                                    // cache-policy hints (bits: 1 partner rows, 2 own/m/v loads, 4 w/m/v stores,
+                                                   // 8 loads of the pre-update copies, 16 stores of them): non-temporal
     float lam, alpha, b1, b2, eps, lr;
 };
 struct RedPair { RedArgs a[2]; };

@@ -53,6 +53,24 @@ __device__ __forceinline__ void store_frag(float* __restrict__ row, int d0, int 
     }
 }
 
+// cache-policy experiments on the big-table step (RedArgs::nt bits; A/B by TFR_NT): runtime-selected hints
+template <int VEC>
+__device__ __forceinline__ Frag<VEC> load_frag_h(const float* __restrict__ row, int d0, int D, bool nt) {
+    return nt ? load_frag<VEC, true>(row, d0, D) : load_frag<VEC, false>(row, d0, D);
+}
+template <int VEC>
+__device__ __forceinline__ void store_frag_h(float* __restrict__ row, int d0, int D, const Frag<VEC>& f, bool nt) {
+    if (!nt) { store_frag<VEC>(row, d0, D, f); return; }
+    if (d0 < D) {
+        if constexpr (VEC == 4) {
+            floatx4 t; t.x = f.v[0]; t.y = f.v[1]; t.z = f.v[2]; t.w = f.v[3];
+            __builtin_nontemporal_store(t, reinterpret_cast<floatx4*>(row + d0));
+        } else {
+            __builtin_nontemporal_store(f.v[0], row + d0);
+        }
+    }
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float x) {
     // butterfly over the G lanes of a group (G is a power of two <= 64); every lane of the
@@ -863,21 +881,21 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         if constexpr (!FWD) gk = a.g[pos];
         const int32_t pid = a.partner_by_pos ? 0 : a.other[pos];     // not needed when the partner row comes by position
         const float lam_e = a.lam_arr ? a.lam_arr[pos] : a.lam;      // FM: lam - g x^2 per non-zero
-        const Frag<VEC> x = a.partner_by_pos ? load_frag<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D)
-                                             : load_frag<VEC>(a.partner + (size_t)pid * D, d0, D);
-        o = load_frag<VEC>(a.own + roff, d0, D);
+        const Frag<VEC> x = a.partner_by_pos ? load_frag_h<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D, a.nt & 8)
+                                             : load_frag_h<VEC>(a.partner + (size_t)pid * D, d0, D, a.nt & 1);
+        o = load_frag_h<VEC>(a.own + roff, d0, D, a.nt & 2);
         ob = a.own_bias[row];
         if constexpr (RMODE == RMODE_ADAM) {
             if (head) {
-                mrow = load_frag<VEC>(a.m + roff, d0, D);
-                vrow = load_frag<VEC>(a.v + roff, d0, D);
+                mrow = load_frag_h<VEC>(a.m + roff, d0, D, a.nt & 2);
+                vrow = load_frag_h<VEC>(a.v + roff, d0, D, a.nt & 2);
                 mb = a.bias_m[row];
                 vb = a.bias_v[row];
             }
         }
         // this side updates its table in place before the other side runs: leave the other side the
         // pre-update row it needs, per entry
-        if (a.own_copy_out) store_frag<VEC>(a.own_copy_out + (size_t)pos * D, d0, D, o);
+        if (a.own_copy_out) store_frag_h<VEC>(a.own_copy_out + (size_t)pos * D, d0, D, o, a.nt & 16);
         if constexpr (FWD) {
             // K1 on the rows already in registers (item side: partner = P[u], own = Q[i]); same
             // arithmetic and order as forward_body
@@ -978,9 +996,9 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             Frag<VEC> w = (FWD && LEAN) ? load_frag<VEC>(a.own_w + roff, d0, D) : o;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], acc.v[q], c);
-            store_frag<VEC>(a.own_w + roff, d0, D, w);
-            store_frag<VEC>(a.m + roff, d0, D, mrow);
-            store_frag<VEC>(a.v + roff, d0, D, vrow);
+            store_frag_h<VEC>(a.own_w + roff, d0, D, w, a.nt & 4);
+            store_frag_h<VEC>(a.m + roff, d0, D, mrow, a.nt & 4);
+            store_frag_h<VEC>(a.v + roff, d0, D, vrow, a.nt & 4);
         }
         if (gl == 0 && !a.frozen_bias) {
             float w = ob;
