@@ -413,10 +413,10 @@ def main():
         if small:
             from tfrecomm_amd import dataparallel
             train, val = gen(U, I, wl["N"])
-            res = dataparallel.bench_entry(wl, K, W, rank, local_rank, world, train, val)
+            res = dataparallel.bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key=args.workload)
         else:
             from tfrecomm_amd import sharded
-            res = sharded.bench_entry(wl, K, W, rank, local_rank, world)
+            res = sharded.bench_entry(wl, K, W, rank, local_rank, world, workload_key=args.workload)
         if rank == 0:
             print(json.dumps(res), flush=True)
         dist.destroy_process_group()

@@ -170,25 +170,37 @@ int tfr_scalars_devptr(tfr_model* m, void** ptr);
 /* ---- row-sharded building blocks: the same kernels, split so the host can put
  *      an RCCL all-to-all between them.  The handle holds ONE rank's shard (user_num /
  *      item_num = local row counts); bias_global is replicated.  All pointers are device
- *      pointers; calls are asynchronous on the model's stream.
+ *      pointers; calls are asynchronous on the model's stream and NONE of them needs a host
+ *      round trip: batch sizes that depend on the data stay on the device, the three exchanges
+ *      use fixed-capacity buffers laid out [world][slot_cap] with rows of tfr_shard_row_stride()
+ *      floats (dim features, the bias, padding to 16 bytes), so they are equal-split all-to-alls.
  *      Semantics per rank and step (ops.py:143-149 applied to the rows this rank owns):
- *        1. owners answer row requests:                  tfr_gather_item_rows
- *        2. forward + backward on the rank's samples (user rows local, item rows fetched and
- *           addressed by slot); user rows are updated in place, item-row gradients (one per
- *           slot, already reduced over this rank's samples) are emitted: tfr_shard_forward_reduce
+ *        0. integer routing of the GLOBAL batch (identical on every rank): the samples whose user
+ *           row this rank owns (owner = id / ceil(rows / world)), the distinct item ids among them
+ *           grouped by owner into request slots (unused slots -1):          tfr_shard_route
+ *        1. owners answer row requests:                                      tfr_shard_gather
+ *        2. forward + backward on the rank's samples (user rows local, item rows addressed by
+ *           slot); user rows are updated in place, item-row gradients (one per slot, already
+ *           reduced over this rank's samples) are emitted in the exchange layout:
+ *                                                                            tfr_shard_forward_reduce
  *        3. owners add the gradient rows received from all ranks (in rank order) and apply the
- *           optimiser to their item rows:                tfr_shard_apply_items
+ *           optimiser to their item rows:                                    tfr_shard_apply_items
  *        4. with the all-reduced {loss, reg, sum_g}: bias_global update, beta powers,
- *           global_step:                                 tfr_shard_finish_step            */
-int tfr_gather_item_rows(tfr_model* m, const int32_t* d_item_local, int64_t n, float* d_rows,
-                         float* d_bias);
-int tfr_shard_forward_reduce(tfr_model* m, const int32_t* d_user_local, const int32_t* d_item_slot,
-                             const float* d_rate, int64_t batch,
-                             const float* d_item_rows, const float* d_item_bias, int64_t n_item_rows,
-                             float* d_logits /* may be NULL */, float* d_item_row_grad,
-                             float* d_item_bias_grad, float* d_scalars4 /* out: loss, reg, sum_g, - */);
-int tfr_shard_apply_items(tfr_model* m, const int32_t* d_item_local, const float* d_grad,
-                          const float* d_bias_grad, int64_t n_rows);
+ *           global_step:                                                     tfr_shard_finish_step
+ *      More local samples than sample_cap, or more distinct items for one owner than slot_cap,
+ *      void the step like an out-of-range id (TFR_ERR_OOB at the next synchronising call). */
+int32_t tfr_shard_row_stride(tfr_model* m);
+int tfr_shard_route(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate, int64_t batch_global,
+                    int32_t rank, int32_t world, int64_t user_num_global, int64_t item_num_global,
+                    int32_t sample_cap, int32_t slot_cap, int32_t* d_req /* out [world * slot_cap] */);
+/* the routed batch, for the caller's bookkeeping and for tests: mine[sample_cap] global batch positions (-1 unused),
+ * u_local[sample_cap], slot[sample_cap], counts = {local samples, distinct items, distinct items per owner [world]} */
+int tfr_shard_routed_devptrs(tfr_model* m, void** mine, void** u_local, void** slot, void** counts);
+int tfr_shard_gather(tfr_model* m, const int32_t* d_req_recv, int64_t n, float* d_rows_out /* [n, stride] */);
+int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows /* [world * slot_cap, stride] */,
+                             float* d_logits /* [sample_cap], may be NULL */, float* d_item_grad /* out, same layout */,
+                             float* d_scalars4 /* out: loss, reg, sum_g, - */);
+int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* d_grad_recv, int64_t n);
 int tfr_shard_finish_step(tfr_model* m, const float* d_scalars4 /* global sums */);
 
 /* ---- data-parallel building blocks (replicated tables, small enough that every GPU holds

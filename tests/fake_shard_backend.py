@@ -1,6 +1,7 @@
-"""Oracle-backed stand-in for tfrecomm_amd.sharded.HipShard (TEST ONLY): the same four calls,
-computed with oracle/svd_oracle.py in float64 on CPU tensors, so the routing / exchange logic of
-sharded.py can run under gloo without a GPU."""
+"""Oracle-backed stand-in for tfrecomm_amd.sharded.HipShard (TEST ONLY): the same calls (route, gather,
+forward_reduce, apply_items, finish_step), computed with NumPy / oracle/svd_oracle.py in float64 on CPU
+tensors, so the exchange logic of sharded.py can run under gloo without a GPU; its `route` is also the
+reference the device routing kernels (csrc/shard.hip) are compared with on the GPU."""
 import numpy as np
 import torch
 
@@ -23,9 +24,48 @@ class OracleShard(object):
     def sync(self):
         pass
 
-    def gather_item_rows(self, ids_local):
-        ids = ids_local.numpy().astype(np.int64)
-        return torch.from_numpy(self.o.Q[ids].copy()), torch.from_numpy(self.o.bi[ids].copy())
+    # ---- routing: the NumPy statement of csrc/shard.hip (what the device kernels must reproduce bit for bit)
+    def route(self, u, i, r, rank, world, U, I, sample_cap, slot_cap):
+        u, i, r = u.numpy().astype(np.int64), i.numpy().astype(np.int64), r.numpy().astype(np.float64)
+        if u.size and (u.min() < 0 or u.max() >= U or i.min() < 0 or i.max() >= I):
+            raise IndexError("user/item id out of range")
+        per_u, per_i = -(-U // world), -(-I // world)
+        own = np.flatnonzero(u // per_u == rank)
+        n = own.size
+        if n > sample_cap:
+            raise IndexError("sample capacity exceeded")
+        uq, inv = np.unique(i[own], return_inverse=True)           # sorted: grouped by owner
+        owner = uq // per_i
+        cnt = np.bincount(owner, minlength=world)
+        if cnt.max(initial=0) > slot_cap:
+            raise IndexError("slot capacity exceeded")
+        start = np.cumsum(cnt) - cnt
+        slot_of_uq = owner * slot_cap + (np.arange(uq.size) - start[owner])
+        req = np.full(world * slot_cap, -1, np.int32)
+        req[slot_of_uq] = (uq - owner * per_i).astype(np.int32)
+        mine = np.full(sample_cap, -1, np.int32); mine[:n] = own
+        u_local = np.full(sample_cap, self.o.U, np.int32); u_local[:n] = u[own] - rank * per_u
+        slot = np.full(sample_cap, world * slot_cap, np.int32); slot[:n] = slot_of_uq[inv]
+        self._r = dict(n=n, u=u[own] - rank * per_u, slot=slot_of_uq[inv], rate=r[own], nslots=world * slot_cap,
+                       mine=torch.from_numpy(mine), u_local=torch.from_numpy(u_local), slot_t=torch.from_numpy(slot),
+                       counts=torch.from_numpy(np.concatenate([[n, uq.size], cnt]).astype(np.int32)))
+        return torch.from_numpy(req)
+
+    def routed(self):
+        return dict(mine=self._r["mine"], u_local=self._r["u_local"], slot=self._r["slot_t"], counts=self._r["counts"])
+
+    @property
+    def stride(self):
+        D = self.o.D
+        return D + 4 if D % 4 == 0 else D + 1
+
+    def gather(self, req_recv):
+        ids = req_recv.numpy().astype(np.int64)
+        out = np.zeros((ids.size, self.stride))
+        ok = ids >= 0
+        out[ok, : self.o.D] = self.o.Q[ids[ok]]
+        out[ok, self.o.D] = self.o.bi[ids[ok]]
+        return torch.from_numpy(out)
 
     def _apply(self, tid, var, ids, occ):
         o = self.o
@@ -39,31 +79,32 @@ class OracleShard(object):
         fn = so.adam_sparse_tf1 if o.adam_mode == so.TF1 else so.adam_sparse_lazy
         fn(var, o.slots[tid], uniq, gsum, o.lr, o.b1p, o.b2p, o.b1, o.b2, o.eps)
 
-    def forward_reduce(self, u_local, slot, rate, item_rows, item_bias):
-        o = self.o
-        u = u_local.numpy().astype(np.int64)
-        s = slot.numpy().astype(np.int64)
-        r = rate.numpy().astype(np.float64)
-        Qf, bif = item_rows.numpy().astype(np.float64), item_bias.numpy().astype(np.float64)
+    def forward_reduce(self, item_rows):
+        o, R = self.o, self._r
+        u, s, r = R["u"].astype(np.int64), R["slot"].astype(np.int64), R["rate"]
+        rows = item_rows.numpy().astype(np.float64)
+        Qf, bif = np.ascontiguousarray(rows[:, : o.D]), np.ascontiguousarray(rows[:, o.D])
         logits = so.forward(o.P, Qf, o.bu, bif, o.mu, u, s, o.item_abs)
         g = so.dlogits(logits, r, o.loss)
         dP, dQ, dbu, dbi, dmu = so.occurrence_grads(o.P, Qf, o.bu, bif, u, s, g, o.reg, o.item_abs, o.reg_bias)
         loss = so.data_loss(logits, r, o.loss) if u.size else 0.0
         reg = so.regularizer(o.P, Qf, o.bu, bif, u, s, o.reg_bias) if u.size else 0.0
-        n = Qf.shape[0]
-        grad = np.zeros((n, o.D))
-        bgrad = np.zeros(n)
-        np.add.at(grad, s, dQ)
-        np.add.at(bgrad, s, dbi)
+        grad = np.zeros((R["nslots"], self.stride))
+        np.add.at(grad[:, : o.D], s, dQ)
+        np.add.at(grad[:, o.D], s, dbi)
         self._apply(so.PF, o.P, u, dP)
         self._apply(so.BU, o.bu, u, dbu)
         scal = torch.tensor([loss, reg, dmu, 0.0], dtype=torch.float64)
-        return torch.from_numpy(grad), torch.from_numpy(bgrad), scal, torch.from_numpy(logits)
+        lg = np.zeros(R["mine"].numel())
+        lg[: R["n"]] = logits
+        return torch.from_numpy(grad), scal, torch.from_numpy(lg)
 
-    def apply_items(self, ids_local, grad, bgrad):
-        ids = ids_local.numpy().astype(np.int64)
-        self._apply(so.QF, self.o.Q, ids, grad.numpy().astype(np.float64))
-        self._apply(so.BI, self.o.bi, ids, bgrad.numpy().astype(np.float64))
+    def apply_items(self, req_recv, grad_recv):
+        ids = req_recv.numpy().astype(np.int64)
+        ok = ids >= 0                                               # buffer order = rank order of the requesters
+        g = grad_recv.numpy().astype(np.float64)
+        self._apply(so.QF, self.o.Q, ids[ok], np.ascontiguousarray(g[ok, : self.o.D]))
+        self._apply(so.BI, self.o.bi, ids[ok], np.ascontiguousarray(g[ok, self.o.D]))
 
     def finish_step(self, scal):
         o = self.o

@@ -41,10 +41,13 @@ def _worker(rank, world, port, kw, U, I, D, B, steps):
             r = (rs.rand(B) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, B).astype(np.float32)
             logits, mine, scal = m.train_step(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev),
                                               torch.from_numpy(r).to(dev))
+            torch.cuda.synchronize()
             wl, wloss, wreg = ref.train_step(u, i, r)
             tol = RTOL * (s + 1)
-            own = mine.cpu().numpy()
-            assert rel_err(logits.cpu().numpy(), wl[own]) <= tol, "logits step %d" % s
+            n = int(m.backend.routed()["counts"][0].item())
+            own = mine.cpu().numpy()[:n]
+            assert np.array_equal(own, np.flatnonzero(u // m.per_u == rank))
+            assert rel_err(logits.cpu().numpy()[:n], wl[own]) <= tol, "logits step %d" % s
             sc = scal.cpu().numpy()
             assert abs(sc[0] - wloss) <= tol * abs(wloss) and abs(sc[1] - wreg) <= tol * abs(wreg)
         m.backend.sync()
@@ -65,6 +68,63 @@ def test_two_rank_sharded_step_matches_oracle(kw):
 def test_two_rank_d128_long_runs():
     mp.spawn(_worker, args=(2, _free_port(), dict(optimizer="adam", adam_mode="lazy"), 40, 30, 128, 3000, 2),
              nprocs=2, join=True)
+
+
+def test_device_routing_is_bit_exact_against_numpy():
+    """csrc/shard.hip (owner filter by stable compaction, distinct items by radix sort, slots grouped by owner) against
+    the NumPy statement in tests/fake_shard_backend.py: every output array, every rank of several worlds, duplicate-heavy
+    and uniform ids, the exact-capacity and the slack-capacity regime, rows that do not divide by the world."""
+    from tfrecomm_amd import sharded
+    from tests.fake_shard_backend import OracleShard
+    dev = torch.device("cuda", 0)
+    cases = [(50, 31, 8, 120, 3, True), (5000, 3001, 16, 4097, 2, True), (100000, 70001, 8, 70000, 4, False),
+             (1000003, 100003, 4, 200000, 8, False), (7, 5, 4, 64, 8, True)]
+    for U, I, D, Bg, world, dup in cases:
+        rs = np.random.RandomState(U)
+        u = dup_heavy_ids(rs, U, Bg) if dup else rs.randint(0, U, Bg).astype(np.int32)
+        i = dup_heavy_ids(rs, I, Bg) if dup else rs.randint(0, I, Bg).astype(np.int32)
+        r = rs.randint(1, 6, Bg).astype(np.float32)
+        tu, ti, tr = torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(r)
+        for rank in sorted({0, world - 1, world // 2}):
+            lo_u, hi_u = sharded.shard_range(U, world, rank)
+            lo_i, hi_i = sharded.shard_range(I, world, rank)
+
+            class _C(object):                            # capacities() needs only rank / world
+                pass
+            c = _C(); c.rank, c.world = rank, world
+            hip = sharded.HipShard(hi_u - lo_u, hi_i - lo_i, D, 0)
+            sh = sharded.ShardedSvd(U, I, D, c, lambda a, b, d: hip, device=dev)
+            sample_cap, slot_cap = sh.capacities(Bg)
+            ora = OracleShard(hi_u - lo_u, hi_i - lo_i, D)
+            want_req = ora.route(tu, ti, tr, rank, world, U, I, sample_cap, slot_cap)
+            got_req = hip.route(tu.to(dev), ti.to(dev), tr.to(dev), rank, world, U, I, sample_cap, slot_cap)
+            hip.sync()
+            assert np.array_equal(got_req.cpu().numpy(), want_req.numpy()), (U, I, world, rank)
+            g, w = hip.routed(), ora.routed()
+            for k in ("counts", "mine", "u_local", "slot"):
+                assert np.array_equal(g[k].cpu().numpy(), w[k].numpy()), (k, U, I, world, rank)
+            hip.model.close()
+
+
+def test_capacity_overflow_voids_the_step_loudly():
+    from tfrecomm_amd import sharded, _lib as L
+    import tfrecomm_amd as T
+    dev = torch.device("cuda", 0)
+    hip = sharded.HipShard(100, 100, 8, 0)
+    rs = np.random.RandomState(0)
+    u = torch.from_numpy(rs.randint(0, 100, 500).astype(np.int32)).to(dev)
+    i = torch.from_numpy(rs.randint(0, 100, 500).astype(np.int32)).to(dev)
+    r = torch.ones(500, device=dev)
+    hip.route(u, i, r, 0, 1, 100, 100, 100, 100)         # 500 local samples, room for 100
+    with pytest.raises(T.TfrError) as e:
+        hip.sync()
+    assert e.value.code == L.ERR_OOB and "capacit" in str(e.value)
+    hip.route(u, i, r, 0, 1, 100, 100, 500, 10)          # ~100 distinct items, 10 slots
+    with pytest.raises(T.TfrError):
+        hip.sync()
+    hip.route(u, i, r, 0, 1, 100, 100, 500, 100)         # fits
+    hip.sync()
+    hip.model.close()
 
 
 # ------------------------------------------------------------------ data parallel (replicated tables)

@@ -42,27 +42,31 @@ def _worker(rank, world, port, kw, U, I, D, B, steps):
             tu, ti, tr = torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(r)
             logits, mine, scal = m.train_step(tu, ti, tr)
             want_logits, want_loss, want_reg = ref.train_step(u, i, r)
-            # ---- routing: bit-exact integer work
-            p = m.last_plan
+            # ---- routing: integer work, exact
+            p = m.backend.routed()
+            sample_cap, slot_cap = m.capacities(B)
             own = np.flatnonzero(u // m.per_u == rank)
-            assert np.array_equal(mine.numpy(), own)
-            assert np.array_equal(p["u_local"].numpy(), (u[own] - m.u_lo).astype(np.int32))
+            n = int(p["counts"][0])
+            assert n == own.size and mine.numel() == sample_cap
+            assert np.array_equal(mine.numpy()[:n], own) and np.all(mine.numpy()[n:] == -1)
+            assert np.array_equal(p["u_local"].numpy()[:n], (u[own] - m.u_lo).astype(np.int32))
             uq = np.unique(i[own])
-            assert np.array_equal(p["uniq"].numpy(), uq)
-            assert np.array_equal(uq[p["slot"].numpy()], i[own])
-            assert np.array_equal(p["send_counts"].numpy(), np.bincount(uq // m.per_i, minlength=world))
+            assert int(p["counts"][1]) == uq.size
+            assert np.array_equal(p["counts"].numpy()[2:], np.bincount(uq // m.per_i, minlength=world))
+            slot = p["slot"].numpy()[:n]
+            assert np.array_equal(slot // slot_cap, i[own] // m.per_i)       # a sample's slot sits in its item owner's block
             counts = [None] * world
             dist.all_gather_object(counts, len(own))
             assert sum(counts) == B                                   # every sample has exactly one owner
             # ---- values
-            assert np.allclose(logits.numpy(), want_logits[own], rtol=1e-12, atol=1e-12)
+            assert np.allclose(logits.numpy()[:n], want_logits[own], rtol=1e-12, atol=1e-12)
             assert abs(scal[0].item() - want_loss) <= 1e-10 * max(1.0, abs(want_loss))
             assert abs(scal[1].item() - want_reg) <= 1e-10 * max(1.0, abs(want_reg))
         got = m.gather_global_tables()
         for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
             assert np.allclose(got[tid], ref.tables()[tid], rtol=1e-10, atol=1e-12), "table %d" % tid
         with pytest.raises(IndexError):
-            m.plan(torch.tensor([U]), torch.tensor([0]))
+            m.train_step(torch.tensor([U], dtype=torch.int32), torch.tensor([0], dtype=torch.int32), torch.tensor([1.0]))
     finally:
         dist.destroy_process_group()
 

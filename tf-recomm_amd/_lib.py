@@ -83,9 +83,12 @@ SIGNATURES = {
     "tfr_set_stream": (C.c_int, [_p, _p]),
     "tfr_get_stream": (C.c_int, [_p, C.POINTER(_p)]),
     "tfr_scalars_devptr": (C.c_int, [_p, C.POINTER(_p)]),
-    "tfr_gather_item_rows": (C.c_int, [_p, _p, C.c_int64, _p, _p]),
-    "tfr_shard_forward_reduce": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _p, C.c_int64, _p, _p, _p, _p]),
-    "tfr_shard_apply_items": (C.c_int, [_p, _p, _p, _p, C.c_int64]),
+    "tfr_shard_row_stride": (C.c_int32, [_p]),
+    "tfr_shard_route": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _p]),
+    "tfr_shard_routed_devptrs": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
+    "tfr_shard_gather": (C.c_int, [_p, _p, C.c_int64, _p]),
+    "tfr_shard_forward_reduce": (C.c_int, [_p, _p, _p, _p, _p]),
+    "tfr_shard_apply_items": (C.c_int, [_p, _p, _p, C.c_int64]),
     "tfr_shard_finish_step": (C.c_int, [_p, _p]),
     "tfr_dp_flat_size": (C.c_int64, [_p]),
     "tfr_dp_local_grads": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _p]),

@@ -108,6 +108,11 @@ struct tfr_model {
     static const int HRING = 4;
     int64_t* h_ring = nullptr; int64_t* d_ring = nullptr; int64_t ring_cap = 0; int ring_pos = 0;
     hipEvent_t ring_ev[HRING] = {nullptr, nullptr, nullptr, nullptr};
+    // row-sharded step: the routed local batch (tfr_shard_route)
+    int32_t *rt_mine = nullptr, *rt_u = nullptr, *rt_it = nullptr, *rt_slot = nullptr, *rt_counts = nullptr;
+    float* rt_r = nullptr;
+    int64_t route_cap = 0, rt_B = 0, rt_slots = 0;
+    int32_t route_world = 0, rt_world = 0;
     // resident validation set (svd_train_val.py:33-38: the whole set is one batch)
     int32_t *ev_u = nullptr, *ev_i = nullptr;
     float* ev_r = nullptr;
@@ -282,6 +287,8 @@ static int check_device_error(tfr_model* m) {
         HIPCHK(hipStreamSynchronize(m->stream));
         if (e & 1) return fail(TFR_ERR_OOB, "user/item id out of range [0,%lld) / [0,%lld)",
                                (long long)m->U, (long long)m->I);
+        if (e & 4) return fail(TFR_ERR_OOB, "row-sharded step: more local samples or distinct items per owner than the fixed capacities "
+                                            "(sample_cap / slot_cap) hold - the step was void; raise the slack");
         return fail(TFR_ERR_OOB, "store index out of range [0,%lld)", (long long)m->N);
     }
     return TFR_OK;
@@ -332,6 +339,7 @@ int tfr_destroy(tfr_model* m) {
     for (auto e : m->chunk_ev) (void)hipEventDestroy(e);
     if (m->ev_ids_free) (void)hipEventDestroy(m->ev_ids_free);
     dfree(m->d_rng); dfree(m->d_ring); dfree(m->d_ids_alt); dfree(m->d_rng_snap);
+    dfree(m->rt_mine); dfree(m->rt_u); dfree(m->rt_it); dfree(m->rt_r); dfree(m->rt_slot); dfree(m->rt_counts);
     if (m->spec_ev) (void)hipEventDestroy(m->spec_ev);
     if (m->h_ring) (void)hipHostFree(m->h_ring);
     for (int z = 0; z < tfr_model::HRING; ++z) if (m->ring_ev[z]) (void)hipEventDestroy(m->ring_ev[z]);
@@ -1339,6 +1347,8 @@ static int ensure_lookahead(tfr_model* m) {
         m->alt_cap = m->cap;
     }
     if (!m->stream2) {
+        // (tried, one gpurun call each, C3 step: a high-priority look-ahead stream - no change; the look-ahead stream
+        // confined to 8 / 16 / 32 / 64 CUs by hipExtStreamCreateWithCUMask - 1070 / 717 / 584 / 487 us against 497-504)
         HIPCHK(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
         for (int z = 0; z < 2; ++z) {
             HIPCHK(hipEventCreateWithFlags(&m->ev_sorted[z], hipEventDisableTiming));
@@ -1835,46 +1845,102 @@ int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t B,
 // ---- row-sharded building blocks --------------------------------------------
 // The model handle holds this rank's shard: user rows [U_local], item rows [I_local].  User
 // rows of a sample are always local (samples are routed to the owner of their user row);
-// item rows are fetched from their owners before, and item-row gradients returned after.
+// item rows are fetched from and their gradients returned to their owners through fixed-capacity
+// exchange buffers laid out [world][slot_cap] rows of tfr_shard_row_stride() floats: D features, the bias, padding.
 
-static int bits_for_rows(int64_t rows) {
-    int b = 1;
-    while (((int64_t)1 << b) < rows && b < 31) ++b;
-    return b;
-}
+static int shard_stride(const tfr_model* m) { return m->VEC == 4 ? m->D + 4 : m->D + 1; }
 
-int tfr_gather_item_rows(tfr_model* m, const int32_t* d_item_local, int64_t n, float* d_rows, float* d_bias) {
+int32_t tfr_shard_row_stride(tfr_model* m) { return m ? shard_stride(m) : 0; }
+
+int tfr_shard_route(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate, int64_t Bg,
+                    int32_t rank, int32_t world, int64_t U_global, int64_t I_global, int32_t sample_cap, int32_t slot_cap,
+                    int32_t* d_req) {
     MODEL_ENTER(m);
-    if (n < 0 || (n > 0 && (!d_item_local || !d_rows || !d_bias))) return fail(TFR_ERR_ARG, "gather_item_rows: bad arguments");
-    if (n == 0) return TFR_OK;
-    GatherRowsArgs g;
-    g.ids = d_item_local; g.table = m->w[TFR_Q]; g.bias = m->w[TFR_BI];
-    g.rows_out = d_rows; g.bias_out = d_bias; g.err = m->d_err; g.n = n; g.rows = m->I; g.D = m->D;
-    launch_gather_rows(g, m->G, m->VEC, m->stream);
+    if (Bg < 0 || world < 1 || rank < 0 || rank >= world || sample_cap < 1 || slot_cap < 1 || !d_req || U_global < 1 || I_global < 1 ||
+        I_global >= 0x7fffffffLL || U_global >= 0x7fffffffLL || (Bg > 0 && (!d_user || !d_item || !d_rate)))
+        return fail(TFR_ERR_ARG, "shard_route: bad arguments");
+    if ((int64_t)world * slot_cap >= 0x7fffffffLL) return fail(TFR_ERR_ARG, "shard_route: world * slot_cap too large");
+    int rc;
+    const int64_t need = sample_cap > (int64_t)world * slot_cap ? sample_cap : (int64_t)world * slot_cap;
+    if ((rc = ensure_capacity(m, need > Bg ? need : (Bg > 0 ? Bg : 1)))) return rc;
+    if (sample_cap > m->route_cap || world > m->route_world) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(m->rt_mine); dfree(m->rt_u); dfree(m->rt_it); dfree(m->rt_r); dfree(m->rt_slot); dfree(m->rt_counts);
+        m->rt_mine = m->rt_u = m->rt_it = m->rt_slot = m->rt_counts = nullptr; m->rt_r = nullptr; m->route_cap = 0;
+        if ((rc = dmalloc(&m->rt_mine, (size_t)sample_cap)) || (rc = dmalloc(&m->rt_u, (size_t)sample_cap)) ||
+            (rc = dmalloc(&m->rt_it, (size_t)sample_cap)) || (rc = dmalloc(&m->rt_r, (size_t)sample_cap)) ||
+            (rc = dmalloc(&m->rt_slot, (size_t)sample_cap)) || (rc = dmalloc(&m->rt_counts, (size_t)world + 4))) return rc;
+        m->route_cap = sample_cap; m->route_world = world;
+    }
+    m->rt_B = sample_cap; m->rt_slots = world * slot_cap; m->rt_world = world;
+    hipStream_t s = m->stream;
+    RouteArgs a;
+    memset(&a, 0, sizeof(a));
+    a.u = d_user; a.it = d_item; a.r = d_rate; a.Bg = Bg; a.U = U_global; a.I = I_global;
+    a.per_u = (U_global + world - 1) / world; a.per_i = (I_global + world - 1) / world; a.u_lo = a.per_u * rank;
+    a.rank = rank; a.world = world; a.Bcap = sample_cap; a.cap = slot_cap;
+    a.u_pad = (int32_t)m->U; a.i_pad = (int32_t)I_global;
+    a.mine = m->rt_mine; a.u_local = m->rt_u; a.it_glob = m->rt_it; a.r_loc = m->rt_r; a.slot = m->rt_slot;
+    a.req = d_req; a.counts = m->rt_counts; a.blk = m->lrank_u; a.err = m->d_err;      // lrank_u: [cap] ints of sort scratch
+    HIPCHK(hipMemsetAsync(d_req, 0xff, (size_t)world * slot_cap * 4, s));             // every slot unused (-1)
+    launch_route_compact(a, s);
+    HIPCHK(hipGetLastError());
+    {   // the local samples sorted by global item id: distinct ids become adjacent and grouped by owner
+        const int32_t* keys[2] = {m->rt_it, nullptr};
+        const int bits[2] = {bits_for(I_global + 1), 0};
+        int32_t* ks[2] = {m->ks_i, nullptr};
+        int32_t* ps[2] = {m->ps_i, nullptr};
+        if ((rc = radix_sort_columns(m, 1, keys, bits, ks, ps, sample_cap))) return rc;
+    }
+    a.ks = m->ks_i; a.ps = m->ps_i;
+    launch_route_slots(a, s);
     HIPCHK(hipGetLastError());
     return TFR_OK;
 }
 
-int tfr_shard_forward_reduce(tfr_model* m, const int32_t* du, const int32_t* dslot, const float* dr, int64_t B,
-                             const float* d_item_rows, const float* d_item_bias, int64_t nI,
-                             float* d_logits, float* d_item_row_grad, float* d_item_bias_grad,
-                             float* d_scalars4) {
+int tfr_shard_routed_devptrs(tfr_model* m, void** mine, void** u_local, void** slot, void** counts) {
     MODEL_ENTER(m);
-    if (B < 0 || nI < 0 || !d_scalars4) return fail(TFR_ERR_ARG, "shard_forward_reduce: bad sizes / null scalars");
-    if (B > 0 && (!du || !dslot || !dr || !d_item_rows || !d_item_bias || !d_item_row_grad || !d_item_bias_grad || nI < 1))
-        return fail(TFR_ERR_ARG, "shard_forward_reduce: null pointer");
+    if (!m->rt_counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
+    if (mine) *mine = m->rt_mine;
+    if (u_local) *u_local = m->rt_u;
+    if (slot) *slot = m->rt_slot;
+    if (counts) *counts = m->rt_counts;
+    return TFR_OK;
+}
+
+int tfr_shard_gather(tfr_model* m, const int32_t* d_req_recv, int64_t n, float* d_rows_out) {
+    MODEL_ENTER(m);
+    if (n < 0 || (n > 0 && (!d_req_recv || !d_rows_out))) return fail(TFR_ERR_ARG, "shard_gather: bad arguments");
+    if (n == 0) return TFR_OK;
+    GatherPackedArgs g;
+    g.ids = d_req_recv; g.table = m->w[TFR_Q]; g.bias = m->w[TFR_BI]; g.out = d_rows_out; g.err = m->d_err;
+    g.n = n; g.rows = m->I; g.D = m->D; g.stride = shard_stride(m);
+    launch_gather_packed(g, m->G, m->VEC, m->stream);
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
+int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_logits, float* d_item_grad, float* d_scalars4) {
+    MODEL_ENTER(m);
+    if (!m->rt_counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
+    if (!d_item_rows || !d_item_grad || !d_scalars4) return fail(TFR_ERR_ARG, "shard_forward_reduce: null pointer");
+    const int64_t B = m->rt_B, nI = m->rt_slots;
+    const int DS = shard_stride(m);
+    const int32_t* du = m->rt_u; const int32_t* dslot = m->rt_slot; const float* dr = m->rt_r;
+    const int32_t* dB = m->rt_counts;                     // the local batch size, on the device
     int rc;
-    if ((rc = ensure_capacity(m, B > nI ? (B > 0 ? B : 1) : nI))) return rc;
+    if ((rc = ensure_capacity(m, B > nI ? B : nI))) return rc;
     const tfr_opts& o = m->o;
     const bool adam = o.optimizer == TFR_OPT_ADAM;
     const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
     hipStream_t s = m->stream;
     int nblk = 0;
-    if (B > 0) {
+    {
         FwdArgs f;
         memset(&f, 0, sizeof(f));
-        f.P = m->w[TFR_P]; f.Q = d_item_rows; f.bu = m->w[TFR_BU]; f.bi = d_item_bias; f.mu = m->w[TFR_MU];
+        f.P = m->w[TFR_P]; f.Q = d_item_rows; f.bu = m->w[TFR_BU]; f.bi = d_item_rows + m->D; f.mu = m->w[TFR_MU];
+        f.qstride = DS; f.bistride = DS; f.dB = dB;
         f.u = du; f.it = dslot; f.r = dr; f.logits = d_logits; f.g = m->d_g; f.partials = m->partials; f.err = m->d_err;
         f.B = B; f.U = m->U; f.I = nI;
         f.D = m->D; f.loss = o.loss; f.item_abs = o.item_abs; f.reg_bias = o.reg_bias;
@@ -1885,23 +1951,23 @@ int tfr_shard_forward_reduce(tfr_model* m, const int32_t* du, const int32_t* dsl
         }
         HIPCHK(hipGetLastError());
         {
-            Prof p(m, TFR_K_SORT);
+            Prof p(m, TFR_K_SORT);                        // unused sample slots carry keys one past the last row: they sort last
             const int32_t* keys[2] = {du, dslot};
-            const int bits[2] = {m->bits_u, bits_for_rows(nI)};
+            const int bits[2] = {bits_for(m->U + 1), bits_for(nI + 1)};
             int32_t* ks[2] = {m->ks_u, m->ks_i};
             int32_t* ps[2] = {m->ps_u, m->ps_i};
             if ((rc = radix_sort_columns(m, 2, keys, bits, ks, ps, B))) return rc;
         }
         RedArgs r;
         memset(&r, 0, sizeof(r));
-        r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D;
+        r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D; r.dB = dB;
         r.item_abs = o.item_abs; r.reg_bias = o.reg_bias;
         r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
         RedPair pr;
         RedArgs ri = r;                 // item side: own = the fetched rows, indexed by slot
         ri.side = 1;
         ri.ks = m->ks_i; ri.ps = m->ps_i; ri.other = du;
-        ri.own = d_item_rows; ri.partner = m->w[TFR_P]; ri.own_bias = d_item_bias;
+        ri.own = d_item_rows; ri.ostride = DS; ri.own_bias = d_item_rows + m->D; ri.obstride = DS; ri.partner = m->w[TFR_P];
         ri.grad_rows = m->gq; ri.grad_bias = m->gbq;
         pr.a[0] = ri;
         {
@@ -1911,12 +1977,12 @@ int tfr_shard_forward_reduce(tfr_model* m, const int32_t* du, const int32_t* dsl
         HIPCHK(hipGetLastError());
         ApplyArgs ap;
         memset(&ap, 0, sizeof(ap));
-        ap.err = m->d_err; ap.B = B; ap.D = m->D;
+        ap.err = m->d_err; ap.B = B; ap.D = m->D; ap.dB = dB;
         ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
         ApplyPair app;
-        app.a[0] = ap;                  // emit one reduced gradient row per slot
+        app.a[0] = ap;                  // emit one reduced gradient row (+ bias gradient) per slot, in the exchange layout
         app.a[0].ks = m->ks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
-        app.a[0].w = d_item_row_grad; app.a[0].bias_w = d_item_bias_grad;
+        app.a[0].w = d_item_grad; app.a[0].wstride = DS; app.a[0].bias_w = d_item_grad + m->D; app.a[0].wbstride = DS;
         {
             Prof p(m, TFR_K_APPLY);
             launch_apply_rows(app, 1, 2, m->G, m->VEC, s);
@@ -1925,7 +1991,7 @@ int tfr_shard_forward_reduce(tfr_model* m, const int32_t* du, const int32_t* dsl
         RedArgs ru = r;                 // user side: rows are local; partner = fetched item rows
         ru.side = 0;
         ru.ks = m->ks_u; ru.ps = m->ps_u; ru.other = dslot;
-        ru.own = m->w[TFR_P]; ru.partner = d_item_rows; ru.own_bias = m->w[TFR_BU];
+        ru.own = m->w[TFR_P]; ru.partner = d_item_rows; ru.pstride = DS; ru.own_bias = m->w[TFR_BU];
         ru.own_w = m->w[TFR_P]; ru.m = m->m[TFR_P]; ru.v = m->v[TFR_P];
         ru.bias_w = m->w[TFR_BU]; ru.bias_m = m->m[TFR_BU]; ru.bias_v = m->v[TFR_BU];
         ru.grad_bias = m->gbp; ru.map = tf1 ? m->map_u : nullptr;
@@ -1975,32 +2041,37 @@ int tfr_shard_forward_reduce(tfr_model* m, const int32_t* du, const int32_t* dsl
     return TFR_OK;
 }
 
-int tfr_shard_apply_items(tfr_model* m, const int32_t* d_item_local, const float* d_grad, const float* d_bias_grad, int64_t n) {
+int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* d_grad_recv, int64_t n) {
     MODEL_ENTER(m);
-    if (n < 0 || (n > 0 && (!d_item_local || !d_grad || !d_bias_grad))) return fail(TFR_ERR_ARG, "shard_apply_items: bad arguments");
+    if (n < 0 || (n > 0 && (!d_req_recv || !d_grad_recv))) return fail(TFR_ERR_ARG, "shard_apply_items: bad arguments");
+    if (!m->rt_counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
     int rc;
     if ((rc = ensure_capacity(m, n > 0 ? n : 1))) return rc;
     const tfr_opts& o = m->o;
     const bool adam = o.optimizer == TFR_OPT_ADAM;
     const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
+    const int DS = shard_stride(m);
     hipStream_t s = m->stream;
+    int32_t* d_nvalid = m->rt_counts + m->rt_world + 2;   // requests actually received (unused slots excluded)
     if (n > 0) {
+        // unused slots (-1) get the key one past the last row: they sort behind every real request and fall outside the count
+        launch_pad_keys(d_req_recv, m->d_i, n, (int32_t)m->I, d_nvalid, s);
+        HIPCHK(hipGetLastError());
         {
             Prof p(m, TFR_K_SORT);
-            const int32_t* keys[2] = {d_item_local, nullptr};
-            const int bits[2] = {m->bits_i, 0};
+            const int32_t* keys[2] = {m->d_i, nullptr};
+            const int bits[2] = {bits_for(m->I + 1), 0};
             int32_t* ks[2] = {m->ks_i, nullptr};
             int32_t* ps[2] = {m->ps_i, nullptr};
-            // column 0 of the helper uses the "user" scratch; results still land in ks_i / ps_i
             if ((rc = radix_sort_columns(m, 1, keys, bits, ks, ps, n))) return rc;
         }
         RedPair pr;
         RedArgs& r = pr.a[0];
         memset(&r, 0, sizeof(r));
-        r.err = m->d_err; r.B = n; r.D = m->D; r.side = 1;
+        r.err = m->d_err; r.B = n; r.D = m->D; r.side = 1; r.dB = d_nvalid;
         r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
-        r.ks = m->ks_i; r.ps = m->ps_i; r.rows_in = d_grad; r.bias_in = d_bias_grad;
+        r.ks = m->ks_i; r.ps = m->ps_i; r.rows_in = d_grad_recv; r.rstride = DS; r.bias_in = d_grad_recv + m->D; r.rbstride = DS;
         r.own = m->w[TFR_Q]; r.own_bias = m->w[TFR_BI];
         r.own_w = m->w[TFR_Q]; r.m = m->m[TFR_Q]; r.v = m->v[TFR_Q];
         r.bias_w = m->w[TFR_BI]; r.bias_m = m->m[TFR_BI]; r.bias_v = m->v[TFR_BI];
@@ -2015,7 +2086,7 @@ int tfr_shard_apply_items(tfr_model* m, const int32_t* d_item_local, const float
             ApplyPair app;
             ApplyArgs& ap = app.a[0];
             memset(&ap, 0, sizeof(ap));
-            ap.err = m->d_err; ap.B = n; ap.D = m->D; ap.only_split = 1;
+            ap.err = m->d_err; ap.B = n; ap.D = m->D; ap.only_split = 1; ap.dB = d_nvalid;
             ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
             ap.ks = m->ks_i; ap.grad_rows = m->gq; ap.grad_bias = m->gbq;
             ap.w = m->w[TFR_Q]; ap.m = m->m[TFR_Q]; ap.v = m->v[TFR_Q];

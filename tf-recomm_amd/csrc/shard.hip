@@ -1,0 +1,206 @@
+// shard.hip - integer routing of the row-sharded step, on the device, with this library's own scan /
+// sort kernels: no host round trip, no torch.unique / nonzero / bincount.
+//
+// Every rank sees the same global batch.  A rank keeps the samples whose USER row it owns (owner = id / per_u, block
+// partition) in batch order, finds the distinct ITEM ids among them (stable radix sort by global item id: sorted ids
+// are grouped by owner because owner = id / per_i is monotone) and lays the requests out as [world][cap]: slot
+// w * cap + k holds the k-th distinct item this rank needs from owner w, as the owner's local row id; unused slots
+// hold -1.  The same slot numbers address the rows that come back (and the gradient rows that return), so all three
+// exchanges are equal-split all-to-alls of fixed size - nothing variable-length ever has to be known on the host.
+// Capacity overflow (more local samples than Bcap, more distinct items for one owner than cap) raises the device
+// error flag: the step is void, like an out-of-range id.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "svd_kernels.h"
+
+namespace tfr {
+
+// block-level exclusive rank of `flag` among the block's 1024 threads (in thread order) + the block's total
+__device__ __forceinline__ int block_rank_1024(bool flag, int* total) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int r = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) before += c; tot += c; }
+    __syncthreads();                                     // wsum may be reused by the caller's next call
+    *total = tot;
+    return before + r;
+}
+
+__device__ __forceinline__ bool route_mine(const RouteArgs& a, int64_t k, bool* bad) {
+    if (k >= a.Bg) return false;
+    const int64_t u = a.u[k], it = a.it[k];
+    if ((uint64_t)u >= (uint64_t)a.U || (uint64_t)it >= (uint64_t)a.I) { *bad = true; return false; }
+    return u / a.per_u == a.rank;
+}
+
+// phase 1a: per 1024-sample block, how many samples are this rank's (and the global range check)
+__global__ __launch_bounds__(1024) void k_route_count(RouteArgs a) {
+    bool bad = false;
+    const bool f = route_mine(a, (int64_t)blockIdx.x * 1024 + threadIdx.x, &bad);
+    int tot;
+    (void)block_rank_1024(f, &tot);
+    if (threadIdx.x == 0) a.blk[blockIdx.x] = tot;
+    if (bad) atomicOr(a.err, 1);
+}
+
+// exclusive scan of blk[0..n) in place by ONE block (n <= a few thousand); total -> *out (clamped to limit, flagging overflow)
+__global__ __launch_bounds__(1024) void k_route_scan(int32_t* blk, int n, int32_t* out, int32_t limit, int32_t* err, int32_t* zero, int nzero) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + 1023) / 1024;
+    int loc = 0;
+    for (int q = 0; q < per; ++q) { const int b = tid * per + q; if (b < n) loc += blk[b]; }
+    int incl = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - loc;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (int q = 0; q < per; ++q) { const int b = tid * per + q; if (b < n) { const int c = blk[b]; blk[b] = run; run += c; } }
+    if (tid == 1023) {
+        int tot = run;
+        if (tot > limit) { atomicOr(err, 4); tot = limit; }
+        *out = tot;
+    }
+    if (tid < nzero) zero[tid] = 0;
+}
+
+// phase 1b: the rank's samples, compacted in batch order; unused sample slots get keys that sort last
+__global__ __launch_bounds__(1024) void k_route_scatter(RouteArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    bool bad = false;
+    const bool f = route_mine(a, k, &bad);
+    int tot;
+    const int r = block_rank_1024(f, &tot);
+    const int dst = a.blk[blockIdx.x] + r;
+    if (f && dst < a.Bcap) {
+        a.mine[dst] = (int32_t)k;
+        a.u_local[dst] = (int32_t)(a.u[k] - a.u_lo);
+        a.it_glob[dst] = a.it[k];
+        a.r_loc[dst] = a.r[k];
+    }
+    // the tail [n_local, Bcap): every block pads a stripe of it
+    const int n_local = a.counts[0];
+    for (int64_t q = (int64_t)n_local + (int64_t)blockIdx.x * 1024 + threadIdx.x; q < a.Bcap; q += (int64_t)gridDim.x * 1024) {
+        a.mine[q] = -1; a.u_local[q] = a.u_pad; a.it_glob[q] = a.i_pad; a.r_loc[q] = 0.f;
+    }
+}
+
+__device__ __forceinline__ bool route_head(const RouteArgs& a, int64_t j, int n_local) {
+    return j < n_local && (j == 0 || a.ks[j] != a.ks[j - 1]);
+}
+
+// phase 2a: run heads (= distinct item ids) per block of the sorted order; distinct items per owner
+__global__ __launch_bounds__(1024) void k_route_heads(RouteArgs a) {
+    const int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int n_local = a.counts[0];
+    const bool h = route_head(a, j, n_local);
+    int tot;
+    (void)block_rank_1024(h, &tot);
+    if (threadIdx.x == 0) a.blk[blockIdx.x] = tot;
+    if (h) atomicAdd(&a.counts[2 + (int)(a.ks[j] / a.per_i)], 1);      // integer counters: the result does not depend on the order
+}
+
+// phase 2b: slot of every local sample, the request list
+__global__ __launch_bounds__(1024) void k_route_slots(RouteArgs a) {
+    const int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int n_local = a.counts[0];
+    const bool h = route_head(a, j, n_local);
+    int tot;
+    const int r = block_rank_1024(h, &tot);
+    if (j >= a.Bcap) return;
+    if (j >= n_local) { a.slot[a.ps[j]] = a.world * a.cap; return; }      // unused sample slot: a key that sorts last
+    const int uidx = a.blk[blockIdx.x] + r + (h ? 0 : -1);               // index of this entry's run among the distinct ids
+    const int32_t id = a.ks[j];
+    const int w = (int)(id / a.per_i);
+    int start = 0;
+    for (int q = 0; q < w; ++q) start += a.counts[2 + q];
+    const int kk = uidx - start;
+    if (kk >= a.cap) { atomicOr(a.err, 4); a.slot[a.ps[j]] = a.world * a.cap; return; }
+    const int sl = w * a.cap + kk;
+    a.slot[a.ps[j]] = sl;
+    if (h) a.req[sl] = (int32_t)(id - (int64_t)w * a.per_i);
+}
+
+void launch_route_compact(const RouteArgs& a, hipStream_t s) {
+    const int nb = (int)((a.Bg + 1023) / 1024);
+    hipLaunchKernelGGL(k_route_count, dim3(nb), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, s, a.blk, nb, a.counts, a.Bcap, a.err, a.counts + 1, a.world + 1);
+    hipLaunchKernelGGL(k_route_scatter, dim3(nb), dim3(1024), 0, s, a);
+}
+
+void launch_route_slots(const RouteArgs& a, hipStream_t s) {
+    const int nb = (a.Bcap + 1023) / 1024;
+    hipLaunchKernelGGL(k_route_heads, dim3(nb), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, s, a.blk, nb, a.counts + 1, (int32_t)0x7fffffff, a.err, (int32_t*)nullptr, 0);
+    hipLaunchKernelGGL(k_route_slots, dim3(nb), dim3(1024), 0, s, a);
+}
+
+// owner side: rows_out[j] = [table[ids[j]] | bias[ids[j]] | pad] (row stride `stride` floats); unused slots (-1) give zeros
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void k_gather_packed(GatherPackedArgs a) {
+    constexpr int GPB = 256 / G;
+    const int gl = threadIdx.x % G, d0 = gl * VEC;
+    bool oob = false;
+    for (int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G; j < a.n; j += (int64_t)gridDim.x * GPB) {
+        const int32_t id = a.ids[j];
+        float* dst = a.out + (size_t)j * a.stride;
+        float v[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = 0.f;
+        float b = 0.f;
+        if (id >= 0) {
+            if ((int64_t)id >= a.rows) oob = true;
+            else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) if (d0 + q < a.D) v[q] = a.table[(size_t)id * a.D + d0 + q];
+                b = a.bias[id];
+            }
+        }
+        if (d0 < a.D) {
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + d0) = make_float4(v[0], v[1], v[2], v[3]);
+            else dst[d0] = v[0];
+        }
+        if (gl == 0) dst[a.D] = b;
+    }
+    if (oob) atomicOr(a.err, 1);
+}
+
+void launch_gather_packed(const GatherPackedArgs& a, int G, int VEC, hipStream_t s) {
+    const int gpb = 256 / G;
+    int64_t nb = (a.n + gpb - 1) / gpb;
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+#define TFR_GP_CASE(g, v) \
+    if (G == g && VEC == v) { hipLaunchKernelGGL((k_gather_packed<g, v>), dim3((int)nb), dim3(256), 0, s, a); return; }
+    TFR_GP_CASE(4, 4) TFR_GP_CASE(8, 4) TFR_GP_CASE(16, 4) TFR_GP_CASE(32, 4) TFR_GP_CASE(64, 4)
+    TFR_GP_CASE(4, 1) TFR_GP_CASE(8, 1) TFR_GP_CASE(16, 1) TFR_GP_CASE(32, 1) TFR_GP_CASE(64, 1)
+#undef TFR_GP_CASE
+}
+
+__global__ __launch_bounds__(256) void k_pad_keys(const int32_t* in, int32_t* out, int64_t n, int32_t pad_key, int32_t* count) {
+    int c = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t id = in[k];
+        out[k] = id < 0 ? pad_key : id;
+        c += id >= 0;
+    }
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);               // integer counter
+}
+
+void launch_pad_keys(const int32_t* ids_in, int32_t* keys_out, int64_t n, int32_t pad_key, int32_t* count, hipStream_t s) {
+    (void)hipMemsetAsync(count, 0, 4, s);
+    int64_t nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_pad_keys, dim3((int)nb), dim3(256), 0, s, ids_in, keys_out, n, pad_key, count);
+}
+
+}  // namespace tfr

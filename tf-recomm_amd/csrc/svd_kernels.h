@@ -22,6 +22,9 @@ struct FwdArgs {
     float* logits; float* g; float* partials; int32_t* err;
     int64_t B, U, I, N;
     int32_t D, loss, item_abs, reg_bias, lds_reduce;
+    // row-sharded step: the batch size lives on the device (dB, <= B), item rows come from the packed exchange
+    // buffer (row stride qstride floats, bias inside the row: bi = Q + D, stride bistride).  0 = D / 1.
+    const int32_t* dB; int32_t qstride, bistride;
 };
 
 struct GatherArgs {
@@ -50,6 +53,11 @@ struct RedArgs {
     int64_t B;
     int32_t D, side, item_abs, reg_bias, frozen_rows, frozen_bias;
     int32_t tile;                                  // >0: the sorted order restarts every `tile` entries
+    // row-sharded step (0 = the plain layout): device-resident entry count, strides of packed exchange buffers
+    const int32_t* dB;                             // entries actually present (<= B)
+    int32_t ostride, obstride;                     // own rows / own bias read-only source (item rows fetched from their owners)
+    int32_t pstride;                               // partner rows
+    int32_t rstride, rbstride;                     // rows_in / bias_in
     int32_t nt;                                    // cache-policy hints (bits: 1 partner rows, 2 own/m/v loads, 4 w/m/v stores,
                                                    // 8 loads of the pre-update copies, 16 stores of them): non-temporal
     float lam, alpha, b1, b2, eps, lr;
@@ -70,6 +78,8 @@ struct ApplyArgs {
     int64_t B;
     int32_t D, frozen_rows, frozen_bias, only_split;   // only_split: runs cut into >1 piece only
     float alpha, b1, b2, eps, lr;
+    const int32_t* dB;                             // row-sharded step: entries actually present (<= B)
+    int32_t wstride, wbstride;                     // OPT 2 (emit reduced rows): output row / bias stride (0 = D / 1)
 };
 struct ApplyPair { ApplyArgs a[2]; };
 
@@ -208,6 +218,31 @@ void launch_pack_triples(const int32_t* u, const int32_t* it, const float* r, vo
 void launch_finalize(const FinArgs& a, hipStream_t s);
 void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s);
 void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s);
+
+// shard.hip: device-side routing of the row-sharded step - which samples of the global batch this rank owns,
+// the distinct item rows they need, grouped by owner into a fixed-capacity request layout [world][cap]
+struct RouteArgs {
+    const int32_t* u; const int32_t* it; const float* r;     // the GLOBAL batch [Bg], identical on every rank
+    int64_t Bg, U, I;                                        // global row counts (range check)
+    int64_t per_u, per_i, u_lo;                              // block partition: owner = id / per
+    int32_t rank, world, Bcap, cap;                          // capacities: local samples, request slots per owner
+    int32_t u_pad, i_pad;                                    // keys of unused sample slots (one past the last row: they sort last)
+    int32_t* mine; int32_t* u_local; int32_t* it_glob; float* r_loc; int32_t* slot;   // [Bcap] outputs
+    int32_t* req;                                            // [world * cap] local item ids at their owner, -1 = unused slot
+    int32_t* counts;                                         // [0] local samples, [1] distinct items, [2 + w] distinct items owned by w
+    int32_t* blk;                                            // scratch [>= ceil(max(Bg, Bcap) / 1024) + 1]
+    const int32_t* ks; const int32_t* ps;                    // local samples sorted by global item id (radix sort between the phases)
+    int32_t* err;                                            // |= 1 id out of range, |= 4 capacity exceeded
+};
+void launch_route_compact(const RouteArgs& a, hipStream_t s);    // mine / u_local / it_glob / r_loc, counts[0]
+void launch_route_slots(const RouteArgs& a, hipStream_t s);      // after the sort: slot, req, counts[1..]
+struct GatherPackedArgs {
+    const int32_t* ids; const float* table; const float* bias; float* out; int32_t* err;
+    int64_t n, rows; int32_t D, stride;
+};
+void launch_gather_packed(const GatherPackedArgs& a, int G, int VEC, hipStream_t s);
+// pads (-1) of a received request list -> `pad_key` (one past the last row, sorts last); counts the real ones
+void launch_pad_keys(const int32_t* ids_in, int32_t* keys_out, int64_t n, int32_t pad_key, int32_t* count, hipStream_t s);
 
 // rng.hip: NumPy's legacy randint(0, rng + 1, (need,)) from the MT19937 state {key[624], pos} at d_state
 void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rng, uint32_t mask, hipStream_t s,

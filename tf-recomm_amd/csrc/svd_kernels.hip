@@ -188,7 +188,9 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
     const int d0 = gl * VEC;
     const int D = a.D;
     // batch positions fit 32 bits (the workspace caps a batch at 2^30 ratings)
-    const int Bn = (int)a.B;
+    const int Bn = a.dB ? *a.dB : (int)a.B;             // row-sharded step: the local batch size lives on the device
+    const size_t qs = a.qstride ? (size_t)a.qstride : (size_t)a.D;      // item rows may sit in a packed exchange buffer
+    const int bis = a.bistride ? a.bistride : 1;
     const int wave_id = block * NW + (threadIdx.x >> 6);
     const int stride = nblocks * NW * SPI;
     const float mu = *a.mu;
@@ -258,7 +260,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             p[j] = load_frag<VEC, PNT>(a.P + (size_t)u[j] * D, d0, D);
-            q[j] = load_frag<VEC>(a.Q + (size_t)it[j] * D, d0, D);
+            q[j] = load_frag<VEC>(a.Q + (size_t)it[j] * qs, d0, D);
         }
         if constexpr (SBIAS) {
             const cfloat_p cbu = (cfloat_p)(uintptr_t)a.bu;
@@ -269,7 +271,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
 #pragma unroll
                 for (int s2 = 0; s2 < SPW; ++s2) {
                     xs[s2] = cbu[__builtin_amdgcn_readlane(u[j], s2 * G)];
-                    ys[s2] = cbi[__builtin_amdgcn_readlane(it[j], s2 * G)];
+                    ys[s2] = cbi[(size_t)__builtin_amdgcn_readlane(it[j], s2 * G) * bis];
                 }
                 bu_[j] = xs[0]; bi_[j] = ys[0];
 #pragma unroll
@@ -285,7 +287,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
                 if (lane / SPW == j) { mu_ = su; mi_ = si; }
             }
             float wx = 0.f, wy = 0.f;
-            if (lane < SPI) { wx = a.bu[mu_]; wy = a.bi[mi_]; }
+            if (lane < SPI) { wx = a.bu[mu_]; wy = a.bi[(size_t)mi_ * bis]; }
 #pragma unroll
             for (int j = 0; j < UNR; ++j) { bu_[j] = __shfl(wx, j * SPW + sub, 64); bi_[j] = __shfl(wy, j * SPW + sub, 64); }
         }
@@ -842,19 +844,22 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     const int D = a.D;
     const int64_t blk0 = (int64_t)blockIdx.x * EPB;
     const int64_t j = blk0 + grp;
-    const bool valid = j < a.B;
+    const int64_t Bn = a.dB ? (int64_t)*a.dB : a.B;      // row-sharded step: the entry count lives on the device
+    const bool valid = j < Bn;
     int32_t row = -1, prev = -2, pos = 0;
     if (valid) {
         row = a.ks[j];
         prev = (j > 0) ? a.ks[j - 1] : -2;
         pos = a.ps[j];
     }
-    if (err || blk0 >= a.B) return;          // an out-of-range id voids the whole step (block-uniform)
+    if (err || blk0 >= Bn) return;           // an out-of-range id voids the whole step (block-uniform)
     // tile mode: the sorted order is per 1024-entry tile, so a run also starts at every tile start
     const bool head = valid && (prev != row || (a.tile && (j % a.tile) == 0));
     const bool pstart = valid && (head || grp == 0);
     const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
     const size_t roff = (size_t)(valid ? row : 0) * D;
+    const size_t ooff = a.ostride ? (size_t)(valid ? row : 0) * a.ostride : roff;     // own rows read from a packed exchange buffer
+    const size_t oboff = a.obstride ? (size_t)(valid ? row : 0) * a.obstride : (size_t)(valid ? row : 0);
 
     Frag<VEC> o, t, mrow, vrow;
     float ob = 0.f, tb = 0.f, mb = 0.f, vb = 0.f;
@@ -864,8 +869,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     if (valid && a.rows_in) {
         // owner side of the sharded step: the contribution is a gradient row already reduced by
         // a peer (it includes that peer's lam * Q[i] terms); just add them up in arrival order
-        t = load_frag<VEC>(a.rows_in + (size_t)pos * D, d0, D);
-        tb = a.bias_in[pos];
+        t = load_frag<VEC>(a.rows_in + (size_t)pos * (a.rstride ? a.rstride : D), d0, D);
+        tb = a.bias_in[(size_t)pos * (a.rbstride ? a.rbstride : 1)];
         o = load_frag<VEC>(a.own + roff, d0, D);
         ob = a.own_bias[row];
         if constexpr (RMODE == RMODE_ADAM) {
@@ -882,9 +887,9 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         const int32_t pid = a.partner_by_pos ? 0 : a.other[pos];     // not needed when the partner row comes by position
         const float lam_e = a.lam_arr ? a.lam_arr[pos] : a.lam;      // FM: lam - g x^2 per non-zero
         const Frag<VEC> x = a.partner_by_pos ? load_frag_h<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D, a.nt & 8)
-                                             : load_frag_h<VEC>(a.partner + (size_t)pid * D, d0, D, a.nt & 1);
-        o = load_frag_h<VEC>(a.own + roff, d0, D, a.nt & 2);
-        ob = a.own_bias[row];
+                                             : load_frag_h<VEC>(a.partner + (size_t)pid * (a.pstride ? a.pstride : D), d0, D, a.nt & 1);
+        o = load_frag_h<VEC>(a.own + ooff, d0, D, a.nt & 2);
+        ob = a.own_bias[oboff];
         if constexpr (RMODE == RMODE_ADAM) {
             if (head) {
                 mrow = load_frag_h<VEC>(a.m + roff, d0, D, a.nt & 2);
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         if (!go) break;
     }
     bool cont = false;                                   // does the run continue in the next block?
-    if (e == EPB && blk0 + EPB < a.B && !(a.tile && ((blk0 + EPB) % a.tile) == 0)) cont = (a.ks[blk0 + EPB] == row);
+    if (e == EPB && blk0 + EPB < Bn && !(a.tile && ((blk0 + EPB) % a.tile) == 0)) cont = (a.ks[blk0 + EPB] == row);
     const bool whole = head && !cont;
     if (RMODE == RMODE_SCRATCH && whole && a.dense_rows) {
         // dense-gradient form (TF1 Adam sweep / data parallel): a run that lies in one block goes
@@ -1075,13 +1080,14 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
     const int gl = threadIdx.x % G;
     const int d0 = gl * VEC;
     const int D = a.D;
+    const int64_t Bn = a.dB ? (int64_t)*a.dB : a.B;      // row-sharded step: the entry count lives on the device
     int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
     int32_t row;
     if (a.only_split) {
         // one lane group per piece boundary p: a run is split iff it crosses one.  The first
         // boundary a run crosses owns it; its head then lies in the PIECE entries before p.
         const int64_t p = (j + 1) * PIECE;
-        if (err || p >= a.B) return;
+        if (err || p >= Bn) return;
         row = a.ks[p];
         if (a.ks[p - 1] != row) return;                  // no run crosses this boundary
         const int64_t lo = p - PIECE;
@@ -1095,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
             if (bits) { j = lo + k + (__ffsll((long long)bits) - 1); break; }
         }
     } else {
-        if (j >= a.B) return;
+        if (j >= Bn) return;
         row = a.ks[j];
         const int32_t prev = (j > 0) ? a.ks[j - 1] : -2;
         if (err || prev == row) return;                  // voided step / not a run head
@@ -1107,9 +1113,9 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
     for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
     if constexpr (OPT == 2) {                            // sharded step: emit the reduced gradient row
         float gb2;
-        const Frag<VEC> tot = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, a.B, j, row, d0, D, gb2);
-        store_frag<VEC>(a.w + roff, d0, D, tot);
-        if (gl == 0) a.bias_w[row] = gb2;
+        const Frag<VEC> tot = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, Bn, j, row, d0, D, gb2);
+        store_frag<VEC>(a.w + (a.wstride ? (size_t)row * a.wstride : roff), d0, D, tot);
+        if (gl == 0) a.bias_w[a.wbstride ? (size_t)row * a.wbstride : (size_t)row] = gb2;
         return;
     }
     if (!a.frozen_rows) {                                // issued before the piece walk
@@ -1120,7 +1126,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
         }
     }
     float gb;
-    const Frag<VEC> gr = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, a.B, j, row, d0, D, gb);
+    const Frag<VEC> gr = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, Bn, j, row, d0, D, gb);
     if (!a.frozen_rows) {
         if constexpr (OPT == 0) {
 #pragma unroll

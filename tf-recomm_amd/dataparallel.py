@@ -89,7 +89,7 @@ class DataParallelSvd(object):
         return scal
 
 
-def bench_entry(wl, K, W, rank, local_rank, world, train, val):
+def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"):
     """bench.py --gpus N (N>1) for tables that fit every GPU: weak scaling, global batch N x B."""
     dev = torch.device("cuda", local_rank)
     U, I, D, B = wl["U"], wl["I"], wl["D"], wl["B"]
@@ -123,13 +123,41 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val):
         el = el.to(dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    # per-phase device times of a few more steps (events on the stream everything is queued on)
+    n_t = min(K, 20)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_t)]
+    for k in range(n_t):
+        s = W + (k % K)
+        ev[k][0].record()
+        flat = be.local_grads(None, None, None, base + s * B * 8, B)
+        ev[k][1].record()
+        dp._all_reduce(flat)
+        ev[k][2].record()
+        be.apply(flat)
+        ev[k][3].record()
+    torch.cuda.synchronize()
+    phases = {name: sum(ev[k][j].elapsed_time(ev[k][j + 1]) for k in range(n_t)) * 1e3 / n_t
+              for j, name in enumerate(("local_grads", "all_reduce", "apply"))}
     sse, _ = be.model.eval(*val)
-    return dict(metric="training ratings/sec, MovieLens-1M SVD dim=64 @1 GPU (+ val RMSE)",
+    nbytes = be.flat.numel() * 4
+    wire = 2.0 * (world - 1) / world * nbytes            # ring / tree all-reduce: bytes each rank sends
+    step_s = elapsed / K
+    xgmi = wire / step_s / 1e9
+    from .sharded import XGMI_EGRESS_GBS
+    return dict(metric="training ratings/sec + val RMSE, MovieLens-1M SVD dim=64, data-parallel over %d GPUs" % world
+                if workload_key == "c2" else "training ratings/sec, %s, data-parallel over %d GPUs" % (wl["name"], world),
                 value=K * B * world / elapsed, unit="ratings/s", n_gpus=world, steps=K, warmup=W,
-                ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                ms_per_step=step_s * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype="f32", data="synthetic",
-                config=dict(workload=wl["name"], users=U, items=I, dim=D, global_batch=B * world, per_gpu_batch=B,
+                config=dict(workload="%s: %s" % (workload_key, wl["name"]), users=U, items=I, dim=D, global_batch=B * world, per_gpu_batch=B,
                             optimizer="adam", adam_mode="tf1", lr=wl["lr"], reg=wl["reg"],
+                            id_stream="np.random.seed(13575); randint(0, N, (world * B,)) per step, each rank takes its slice (pre-staged)",
                             parallelism="dp%d: replicated tables, one %.1f MB gradient all-reduce (RCCL) per step"
-                                        % (world, be.flat.numel() * 4 / 1e6)),
-                val_rmse=float(np.sqrt(sse / len(val[0]))), roofline=None, cpu_baseline=None)
+                                        % (world, nbytes / 1e6)),
+                val_rmse=float(np.sqrt(sse / len(val[0]))),
+                roofline=dict(kernel="all_reduce (RCCL over xGMI)", bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
+                              frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire, phases_us=phases,
+                              note="bytes each rank sends per step, 2 (N-1)/N x the %.1f MB gradient buffer, over the whole step time; the "
+                                   "2.6 MB model makes this step latency-bound (collective launch + a few link hops), not bandwidth-bound; "
+                                   "with world=1 nothing crosses a link" % (nbytes / 1e6)),
+                cpu_baseline=None)

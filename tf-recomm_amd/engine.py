@@ -238,17 +238,27 @@ class SvdModel:
         L.check(self._lib.tfr_train_step_dev(self._h, d_user, d_item, d_rate, batch, d_logits))
 
     # -- row-sharded building blocks (device pointers; see include/tfrecomm.h) ------
-    def gather_item_rows(self, d_item_local, n, d_rows, d_bias):
-        L.check(self._lib.tfr_gather_item_rows(self._h, d_item_local, n, d_rows, d_bias))
+    def shard_row_stride(self):
+        return int(self._lib.tfr_shard_row_stride(self._h))
 
-    def shard_forward_reduce(self, d_user_local, d_item_slot, d_rate, batch, d_item_rows, d_item_bias,
-                             n_item_rows, d_logits, d_item_row_grad, d_item_bias_grad, d_scalars4):
-        L.check(self._lib.tfr_shard_forward_reduce(self._h, d_user_local, d_item_slot, d_rate, batch, d_item_rows,
-                                                   d_item_bias, n_item_rows, d_logits, d_item_row_grad,
-                                                   d_item_bias_grad, d_scalars4))
+    def shard_route(self, d_user, d_item, d_rate, batch_global, rank, world, user_num_global, item_num_global,
+                    sample_cap, slot_cap, d_req):
+        L.check(self._lib.tfr_shard_route(self._h, d_user, d_item, d_rate, batch_global, rank, world, user_num_global,
+                                          item_num_global, sample_cap, slot_cap, d_req))
 
-    def shard_apply_items(self, d_item_local, d_grad, d_bias_grad, n):
-        L.check(self._lib.tfr_shard_apply_items(self._h, d_item_local, d_grad, d_bias_grad, n))
+    def shard_routed_devptrs(self):
+        ps = [L._p() for _ in range(4)]
+        L.check(self._lib.tfr_shard_routed_devptrs(self._h, *[C.byref(p) for p in ps]))
+        return tuple(p.value for p in ps)
+
+    def shard_gather(self, d_req_recv, n, d_rows_out):
+        L.check(self._lib.tfr_shard_gather(self._h, d_req_recv, n, d_rows_out))
+
+    def shard_forward_reduce(self, d_item_rows, d_logits, d_item_grad, d_scalars4):
+        L.check(self._lib.tfr_shard_forward_reduce(self._h, d_item_rows, d_logits, d_item_grad, d_scalars4))
+
+    def shard_apply_items(self, d_req_recv, d_grad_recv, n):
+        L.check(self._lib.tfr_shard_apply_items(self._h, d_req_recv, d_grad_recv, n))
 
     def shard_finish_step(self, d_scalars4):
         L.check(self._lib.tfr_shard_finish_step(self._h, d_scalars4))

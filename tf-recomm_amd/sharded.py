@@ -1,6 +1,6 @@
 """Row-sharded SVD training across the GPUs of one node: one process per GPU,
 ``torch.distributed`` (backend "nccl" = RCCL over xGMI) for the exchanges, the HIP kernels of
-this package for everything else.
+this package for everything else - including the integer routing.
 
 Partition: block row-sharding - ``owner = id // ceil(rows / world)`` - of ``user_features`` /
 ``user_bias`` by user id and of ``item_features`` / ``item_bias`` by item id, Adam slots
@@ -9,22 +9,28 @@ co-located with their rows, ``bias_global`` replicated.
 One step on the *global* batch (every rank sees the same ids; the reference has no distributed
 path, the semantics are those of one ``minimize`` on the whole batch, ops.py:143-149):
 
-  1. every rank keeps the samples whose USER row it owns (integer routing, no communication);
-  2. it de-duplicates the item ids of its samples and asks their owners for the rows:
-     all-to-all of ids (int32), owners gather, all-to-all of rows ``[n, D]`` + biases back;
-  3. forward + backward locally (``tfr_shard_forward_reduce``): user rows are updated in place,
-     item-row gradients - already reduced over the rank's own samples - come out per slot;
-  4. all-to-all of the gradient rows back to the owners, which add them in rank order
-     (deterministic) and apply the optimiser (``tfr_shard_apply_items``);
-  5. all-reduce of 3 scalars (loss, regulariser, sum g) -> ``bias_global`` update everywhere.
+  0. ``route``: every rank keeps the samples whose USER row it owns and lays the distinct ITEM ids
+     among them out as requests ``[world][slot_cap]`` (slot ``w * slot_cap + k`` = the k-th distinct
+     item this rank needs from owner ``w``; unused slots hold -1).  Device kernels (csrc/shard.hip);
+  1. all-to-all of the request slots (int32), owners ``gather`` the rows: one packed row per slot =
+     ``dim`` features, the bias, padding to 16 bytes;  all-to-all of the rows back;
+  2. ``forward_reduce`` locally: user rows are updated in place, item-row gradients - already reduced
+     over the rank's own samples - come out per slot in the same packed layout;
+  3. all-to-all of the gradient rows to the owners, which add them in rank order (deterministic) and
+     apply the optimiser (``apply_items``);
+  4. all-reduce of 3 scalars (loss, regulariser, sum g) -> ``bias_global`` update everywhere.
 
-Wire volume per rank and step is ~``2 * (D+1) * 4`` bytes per distinct non-local item row, each
-way (fetching user rows as well would double it).  An all-to-all maps one-to-one onto the 7
-direct xGMI links of a GPU; the path is xGMI-bound, not HBM-bound.
+Three equal-split all-to-alls and one 16-byte all-reduce per step, and NO host synchronisation: the
+capacities are fixed, how many slots / samples are really in use stays on the device.  A step that
+overflows a capacity is void and reported like an out-of-range id at the next sync.
 
-The compute backend is injected so the routing/exchange logic can be exercised on CPU with
-``gloo`` (tests/test_sharded_cpu.py uses an oracle-backed stand-in; the product backend is
-``HipShard`` below and has no CPU path).
+Wire volume per rank and step is ``2 * stride * 4`` bytes per request slot each way (fetching user
+rows as well would double it).  An all-to-all maps one-to-one onto the 7 direct xGMI links of a
+GPU; the path is xGMI-bound, not HBM-bound.
+
+The compute backend is injected so the exchange logic can be exercised on CPU with ``gloo``
+(tests/test_sharded_cpu.py uses an oracle-backed stand-in; the product backend is ``HipShard`` below
+and has no CPU path).
 """
 from __future__ import annotations
 
@@ -39,6 +45,8 @@ import torch.distributed as dist
 from . import _lib as L
 from .engine import SvdModel
 
+XGMI_EGRESS_GBS = 7 * 153.0          # MI355X: 7 point-to-point links x ~153 GB/s per GPU
+
 
 def rows_per_rank(rows, world):
     return int(math.ceil(rows / world))
@@ -50,8 +58,13 @@ def shard_range(rows, world, rank):
     return lo, min(rows, lo + per)
 
 
+def packed_stride(dim):
+    """floats per exchanged row: the features, the bias, padding to 16 bytes (csrc/api.hip shard_stride)"""
+    return dim + 4 if dim % 4 == 0 else dim + 1
+
+
 class Comm(object):
-    """all-to-all-v / all-reduce over ``torch.distributed``.  With a CPU-only backend (gloo)
+    """equal-split all-to-all / all-reduce over ``torch.distributed``.  With a CPU-only backend (gloo)
     device tensors are staged through host memory - the rehearsal path; RCCL takes them as is."""
 
     def __init__(self, group=None):
@@ -60,32 +73,17 @@ class Comm(object):
         self.rank = dist.get_rank(group)
         self.stage = dist.get_backend(group) == "gloo"
 
-    def _a2a(self, out, inp, out_splits=None, in_splits=None):
+    def all_to_all(self, inp, out=None):
+        """``inp`` = ``world`` equal chunks along dim 0, chunk w for rank w; returns the chunks received, by source."""
+        if out is None:
+            out = torch.empty_like(inp)
         if self.stage and inp.is_cuda:
             o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            dist.all_to_all_single(o, inp.cpu(), group=self.group)
             out.copy_(o)
         else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            dist.all_to_all_single(out, inp, group=self.group)
         return out
-
-    def exchange_counts(self, send_counts):
-        """send_counts: int64 [world] on the host -> recv_counts [world] on the host."""
-        if self.stage:
-            out = torch.empty_like(send_counts)
-            dist.all_to_all_single(out, send_counts, group=self.group)
-            return out
-        dev = torch.device("cuda", torch.cuda.current_device())
-        out = torch.empty(self.world, dtype=torch.int64, device=dev)
-        dist.all_to_all_single(out, send_counts.to(dev), group=self.group)
-        return out.cpu()
-
-    def all_to_all_v(self, inp, send_counts, recv_counts):
-        """rows of ``inp`` grouped by destination rank (send_counts[w] rows to rank w) ->
-        rows grouped by source rank."""
-        n_out = int(recv_counts.sum())
-        out = torch.empty((n_out,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
-        return self._a2a(out, inp.contiguous(), [int(c) for c in recv_counts], [int(c) for c in send_counts])
 
     def all_reduce_sum(self, t):
         if self.stage and t.is_cuda:
@@ -110,38 +108,74 @@ class HipShard(object):
         self.model = SvdModel(max(1, u_rows), max(1, i_rows), dim, device=device, **opts)
         self.stream = torch.cuda.Stream(device=self.device)
         self.model.set_stream(self.stream.cuda_stream)
+        self.stride = self.model.shard_row_stride()
+        self._buf = {}
+        self._routed = None
+
+    # The model's kernels run on self.stream.  When the caller has made that torch's current stream (bench_entry
+    # does) the collectives order themselves against it and no cross-stream events are needed; otherwise fence.
+    def _foreign(self):
+        cur = torch.cuda.current_stream(self.device)
+        return None if cur == self.stream else cur
 
     def _sync_in(self):
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        cur = self._foreign()
+        if cur is not None:
+            self.stream.wait_stream(cur)
 
     def _sync_out(self):
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        cur = self._foreign()
+        if cur is not None:
+            cur.wait_stream(self.stream)
 
-    def gather_item_rows(self, ids_local):
-        n = ids_local.numel()
-        rows = torch.empty((n, self.D), dtype=torch.float32, device=self.device)
-        bias = torch.empty((n,), dtype=torch.float32, device=self.device)
+    def _get(self, name, shape, dtype):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buf[name] = t
+        return t
+
+    def route(self, u, i, r, rank, world, U, I, sample_cap, slot_cap):
+        req = self._get("req", (world * slot_cap,), torch.int32)
         self._sync_in()
-        self.model.gather_item_rows(ids_local.data_ptr(), n, rows.data_ptr(), bias.data_ptr())
+        self.model.shard_route(u.data_ptr(), i.data_ptr(), r.data_ptr(), u.numel(), rank, world, U, I, sample_cap, slot_cap,
+                               req.data_ptr())
         self._sync_out()
-        return rows, bias
+        self._routed = (sample_cap, world)
+        return req
 
-    def forward_reduce(self, u_local, slot, rate, item_rows, item_bias):
-        B, n = u_local.numel(), item_rows.shape[0]
-        grad = torch.empty((n, self.D), dtype=torch.float32, device=self.device)
-        bgrad = torch.empty((n,), dtype=torch.float32, device=self.device)
-        logits = torch.empty((B,), dtype=torch.float32, device=self.device)
-        scal = torch.zeros((4,), dtype=torch.float32, device=self.device)
+    def routed(self):
+        """views of the routed batch (test / bookkeeping): mine, u_local, slot [sample_cap]; counts [2 + world]"""
+        cap, world = self._routed
+        ptrs = self.model.shard_routed_devptrs()
+
+        def view(ptr, n):
+            iface = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 3}
+            holder = type("_V", (), {"__cuda_array_interface__": iface})()
+            return torch.as_tensor(holder, device=self.device)
+        return dict(mine=view(ptrs[0], cap), u_local=view(ptrs[1], cap), slot=view(ptrs[2], cap), counts=view(ptrs[3], 2 + world))
+
+    def gather(self, req_recv):
+        n = req_recv.numel()
+        rows = self._get("rows_out", (n, self.stride), torch.float32)
         self._sync_in()
-        self.model.shard_forward_reduce(u_local.data_ptr(), slot.data_ptr(), rate.data_ptr(), B,
-                                        item_rows.data_ptr(), item_bias.data_ptr(), n, logits.data_ptr(),
-                                        grad.data_ptr(), bgrad.data_ptr(), scal.data_ptr())
+        self.model.shard_gather(req_recv.data_ptr(), n, rows.data_ptr())
         self._sync_out()
-        return grad, bgrad, scal, logits
+        return rows
 
-    def apply_items(self, ids_local, grad, bgrad):
+    def forward_reduce(self, item_rows):
+        cap, _ = self._routed
+        grad = self._get("grad", tuple(item_rows.shape), torch.float32)
+        logits = self._get("logits", (cap,), torch.float32)
+        scal = self._get("scal", (4,), torch.float32)
         self._sync_in()
-        self.model.shard_apply_items(ids_local.data_ptr(), grad.data_ptr(), bgrad.data_ptr(), ids_local.numel())
+        self.model.shard_forward_reduce(item_rows.data_ptr(), logits.data_ptr(), grad.data_ptr(), scal.data_ptr())
+        self._sync_out()
+        return grad, scal, logits
+
+    def apply_items(self, req_recv, grad_recv):
+        self._sync_in()
+        self.model.shard_apply_items(req_recv.data_ptr(), grad_recv.data_ptr(), req_recv.numel())
         self._sync_out()
 
     def finish_step(self, scal):
@@ -161,9 +195,10 @@ class HipShard(object):
 
 class ShardedSvd(object):
     """One rank of the row-sharded model.  ``backend_factory(u_rows, i_rows, dim)`` builds the
-    compute backend for the local shard."""
+    compute backend for the local shard.  ``slack``: head-room of the fixed capacities over their expected
+    fill at uniform ids (batches up to 65536 use exact upper bounds instead and can never overflow)."""
 
-    def __init__(self, user_num, item_num, dim, comm, backend_factory, device="cpu"):
+    def __init__(self, user_num, item_num, dim, comm, backend_factory, device="cpu", slack=1.5):
         self.U, self.I, self.D = int(user_num), int(item_num), int(dim)
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
@@ -172,7 +207,8 @@ class ShardedSvd(object):
         self.i_lo, self.i_hi = shard_range(self.I, self.world, self.rank)
         self.device = torch.device(device)
         self.backend = backend_factory(self.u_hi - self.u_lo, self.i_hi - self.i_lo, self.D)
-        self.last_plan = None
+        self.slack = float(slack)
+        self.timers = None                                # optional: list collecting (phase, start event, end event)
 
     # -- tables -------------------------------------------------------------------------
     def set_tables_from_global(self, mu, bu, bi, P, Q):
@@ -181,7 +217,7 @@ class ShardedSvd(object):
         P, Q = np.asarray(P, np.float32), np.asarray(Q, np.float32)
         bu, bi = np.asarray(bu, np.float32), np.asarray(bi, np.float32)
 
-        def sl(x, lo, hi, width=None):
+        def sl(x, lo, hi):
             part = x[lo:hi]
             if part.shape[0] == 0:                      # an empty shard keeps one dummy row
                 part = np.zeros((1,) + x.shape[1:], np.float32)
@@ -192,44 +228,69 @@ class ShardedSvd(object):
     def local_tables(self):
         return self.backend.tables()
 
-    # -- routing (integer work, bit-exact) ----------------------------------------------
-    def plan(self, u, i):
-        """Which samples of the global batch this rank owns, their item slots and the request
-        lists.  Pure integer torch ops; deterministic."""
-        u, i = u.to(torch.int64), i.to(torch.int64)
-        if u.numel() and (int(u.min()) < 0 or int(u.max()) >= self.U or int(i.min()) < 0 or int(i.max()) >= self.I):
-            raise L.OutOfRangeError(L.ERR_OOB, "user/item id out of range [0,%d) / [0,%d)" % (self.U, self.I))
-        mine = torch.nonzero(torch.div(u, self.per_u, rounding_mode="floor") == self.rank).reshape(-1)
-        u_local = (u[mine] - self.u_lo).to(torch.int32)
-        uniq, slot = torch.unique(i[mine], sorted=True, return_inverse=True)     # sorted => grouped by owner
-        owner = torch.div(uniq, self.per_i, rounding_mode="floor")
-        send_counts = torch.bincount(owner, minlength=self.world).to(torch.int64).cpu()
-        req_local = (uniq - owner * self.per_i).to(torch.int32)
-        return dict(mine=mine, u_local=u_local, slot=slot.to(torch.int32), uniq=uniq, req_local=req_local,
-                    send_counts=send_counts)
+    # -- capacities -----------------------------------------------------------------------
+    def capacities(self, batch_global):
+        """(sample_cap, slot_cap): fixed sizes of the routed batch and of one owner's request slots"""
+        Bg, W = int(batch_global), self.world
+        if Bg <= 65536:                                   # small: exact upper bounds
+            sample_cap = max(1, Bg)
+            return sample_cap, max(1, min(self.per_i, sample_cap))
+        sample_cap = min(Bg, int(self.slack * Bg / W) + 4096)
+        return sample_cap, max(1, min(self.per_i, int(self.slack * Bg / (W * W)) + 1024))
+
+    def _phase(self, name):
+        if self.timers is None:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, e0)
+
+    def _end(self, tok):
+        if tok is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.timers.append((tok[0], tok[1], e1))
 
     # -- one step ------------------------------------------------------------------------
     def train_step(self, u, i, r):
-        """``u, i, r``: the GLOBAL batch (identical on every rank), torch tensors on this rank's
-        device.  Returns (logits of this rank's samples, their batch positions, global
-        {loss, reg}) - the pre-update logits, like sess.run([train_op, logits])."""
+        """``u, i, r``: the GLOBAL batch (identical on every rank; int32, int32, float32 tensors on this rank's
+        device).  Returns (logits [sample_cap], mine [sample_cap], global {loss, reg, sum g, -}): the pre-update
+        logits of this rank's samples and their positions in the global batch; the first ``counts[0]`` entries
+        are in use (``backend.routed()["counts"]``, on the device - nothing here waits for the host)."""
         c, be = self.comm, self.backend
-        p = self.plan(u, i)
-        self.last_plan = p
-        recv_counts = c.exchange_counts(p["send_counts"])
-        req_recv = c.all_to_all_v(p["req_local"], p["send_counts"], recv_counts)     # ids asked of me
-        rows_out, bias_out = be.gather_item_rows(req_recv)
-        item_rows = c.all_to_all_v(rows_out, recv_counts, p["send_counts"])
-        item_bias = c.all_to_all_v(bias_out, recv_counts, p["send_counts"])
-        rate = r[p["mine"]].to(torch.float32).contiguous()
-        grad, bgrad, scal, logits = be.forward_reduce(p["u_local"].contiguous(), p["slot"].contiguous(), rate,
-                                                      item_rows, item_bias)
-        grad_recv = c.all_to_all_v(grad, p["send_counts"], recv_counts)              # rank order = fixed add order
-        bgrad_recv = c.all_to_all_v(bgrad, p["send_counts"], recv_counts)
-        be.apply_items(req_recv, grad_recv, bgrad_recv)
+        sample_cap, slot_cap = self.capacities(u.numel())
+        t = self._phase("route")
+        req = be.route(u, i, r, self.rank, self.world, self.U, self.I, sample_cap, slot_cap)
+        self._end(t)
+        t = self._phase("all_to_all ids")
+        req_recv = c.all_to_all(req)                                       # slots asked of me, by requester
+        self._end(t)
+        t = self._phase("gather")
+        rows_out = be.gather(req_recv)
+        self._end(t)
+        t = self._phase("all_to_all rows")
+        item_rows = c.all_to_all(rows_out)                                 # chunk w = the rows owner w holds for my slots
+        self._end(t)
+        t = self._phase("forward_reduce")
+        grad, scal, logits = be.forward_reduce(item_rows)
+        self._end(t)
+        t = self._phase("all_to_all grads")
+        grad_recv = c.all_to_all(grad)                                     # by requester: rank order = fixed add order
+        self._end(t)
+        t = self._phase("apply_items")
+        be.apply_items(req_recv, grad_recv)
+        self._end(t)
+        t = self._phase("all_reduce + finish")
         scal = c.all_reduce_sum(scal)
         be.finish_step(scal)
-        return logits, p["mine"], scal
+        self._end(t)
+        return logits, be.routed()["mine"], scal
+
+    def wire_bytes_per_step(self, batch_global):
+        """bytes this rank sends over xGMI per step (requests + rows + gradient rows to the world-1 peers)"""
+        _, slot_cap = self.capacities(batch_global)
+        stride = packed_stride(self.D)
+        return (self.world - 1) * slot_cap * (4 + 2 * stride * 4)
 
     def gather_global_tables(self):
         """All ranks' shards concatenated on every rank (tests / checkpoints)."""
@@ -246,9 +307,10 @@ class ShardedSvd(object):
 
 
 # ------------------------------------------------------------------------------------ bench
-def bench_entry(wl, K, W, rank, local_rank, world):
-    """bench.py --gpus N (N>1): weak scaling - every rank owns 1/N of the rows and the global batch
-    is N x the single-GPU batch, so per-GPU work is fixed.  Returns the JSON dict (rank 0 prints)."""
+def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
+    """bench.py --gpus N (N>1) for tables at the scale sharding is meant for: weak scaling - every rank owns 1/N of
+    the rows and the global batch is N x the single-GPU batch, so per-GPU work is fixed.  Returns the JSON dict
+    (rank 0 prints)."""
     import torch.cuda
     dev = torch.device("cuda", local_rank)
     comm = Comm()
@@ -257,7 +319,9 @@ def bench_entry(wl, K, W, rank, local_rank, world):
     opts = dict(optimizer="adam", adam_mode=wl["adam_mode"], lr=wl["lr"], reg=wl["reg"])
     m = ShardedSvd(U, I, D, comm, lambda ur, ir, d: HipShard(ur, ir, d, local_rank, **opts), device=dev)
     m.backend.model.init_tables(seed=13575 + rank)
-    # the same synthetic store and id stream on every rank (seeded), resident in HBM
+    torch.cuda.set_stream(m.backend.stream)             # collectives queue behind the model's kernels: no fences
+    # the same synthetic store and id stream on every rank (seeded), resident in HBM; every rank gathers the
+    # global batch from its own copy (12 bytes per rating, no communication)
     g = torch.Generator(device=dev)
     g.manual_seed(13575)
     N = min(wl["N"], 50_000_000)
@@ -286,12 +350,31 @@ def bench_entry(wl, K, W, rank, local_rank, world):
         el = el.to(dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    return dict(metric="training ratings/sec, MovieLens-1M SVD dim=64 @1 GPU (+ val RMSE)", value=K * Bg / elapsed,
-                unit="ratings/s", n_gpus=world, steps=K, warmup=W, ms_per_step=elapsed / K * 1e3,
+    # per-phase device times of a few more steps (events on the stream everything is queued on)
+    m.timers = []
+    for s in range(min(K, 10)):
+        step(W + (s % K))
+    torch.cuda.synchronize()
+    phases = {}
+    for name, e0, e1 in m.timers:
+        phases[name] = phases.get(name, 0.0) + e0.elapsed_time(e1) * 1e3 / min(K, 10)
+    m.timers = None
+    wire = m.wire_bytes_per_step(Bg)
+    step_s = elapsed / K
+    exch_us = sum(v for k, v in phases.items() if k.startswith("all_to_all"))
+    xgmi = wire / step_s / 1e9
+    sample_cap, slot_cap = m.capacities(Bg)
+    return dict(metric="training ratings/sec, %s, row-sharded over %d GPUs" % (wl["name"], world), value=K * Bg / elapsed,
+                unit="ratings/s", n_gpus=world, steps=K, warmup=W, ms_per_step=step_s * 1e3,
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                config=dict(workload=wl["name"], users=U, items=I, dim=D, global_batch=Bg, per_gpu_batch=B,
-                            optimizer="adam", adam_mode=wl["adam_mode"],
-                            parallelism="row-sharded tables x%d, all-to-all row fetch + gradient return over RCCL" % world,
-                            note="tables of this size fit one GPU thousands of times over: the exchange latency, not "
-                                 "HBM, bounds the step (SURVEY 8e); --workload c3 is the scale sharding is meant for"),
-                roofline=None, cpu_baseline=None)
+                config=dict(workload="%s: %s" % (workload_key, wl["name"]), users=U, items=I, dim=D, global_batch=Bg, per_gpu_batch=B,
+                            optimizer="adam", adam_mode=wl["adam_mode"], sample_cap=sample_cap, slot_cap=slot_cap,
+                            parallelism="row-sharded tables x%d: device-side routing, 3 equal-split all-to-alls (request slots, "
+                                        "packed rows, packed gradient rows) + one 16-byte all-reduce per step over RCCL, no host sync" % world),
+                roofline=dict(kernel="all_to_all (RCCL over xGMI)", bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
+                              frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire,
+                              exchange_us_per_step=exch_us, phases_us=phases,
+                              note="egress bytes per rank and step (fixed-capacity slots: %d of them to each of %d peers, %d B each way per slot) "
+                                   "over the whole step time; 7 links x 153 GB/s per GPU; with world=1 nothing crosses a link"
+                                   % (slot_cap, world - 1, 2 * packed_stride(D) * 4 + 4)),
+                cpu_baseline=None)
