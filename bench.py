@@ -382,10 +382,23 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("TFR_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                t = torch.zeros(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(t)
+                dist.all_to_all_single(torch.empty_like(t.repeat(world)), t.repeat(world))
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     if args.workload == "als":
         print(json.dumps(als_bench(local_rank)), flush=True)

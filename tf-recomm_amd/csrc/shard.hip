@@ -104,7 +104,18 @@ __global__ __launch_bounds__(1024) void k_route_heads(RouteArgs a) {
     int tot;
     (void)block_rank_1024(h, &tot);
     if (threadIdx.x == 0) a.blk[blockIdx.x] = tot;
-    if (h) atomicAdd(&a.counts[2 + (int)(a.ks[j] / a.per_i)], 1);      // integer counters: the result does not depend on the order
+    // distinct items per owner: counted per block in LDS first (a block of the sorted order spans one or two owners, and a
+    // quarter of a million atomics on one global word take milliseconds), then one global add per owner and block.
+    // Integer counters: the result does not depend on the order.
+    __shared__ int ocnt[64];
+    if (threadIdx.x < 64) ocnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (h) {
+        const int w = (int)(a.ks[j] / a.per_i);
+        if (w < 64) atomicAdd(&ocnt[w], 1); else atomicAdd(&a.counts[2 + w], 1);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.world && threadIdx.x < 64 && ocnt[threadIdx.x]) atomicAdd(&a.counts[2 + threadIdx.x], ocnt[threadIdx.x]);
 }
 
 // phase 2b: slot of every local sample, the request list

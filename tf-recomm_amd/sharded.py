@@ -198,7 +198,7 @@ class ShardedSvd(object):
     compute backend for the local shard.  ``slack``: head-room of the fixed capacities over their expected
     fill at uniform ids (batches up to 65536 use exact upper bounds instead and can never overflow)."""
 
-    def __init__(self, user_num, item_num, dim, comm, backend_factory, device="cpu", slack=1.5):
+    def __init__(self, user_num, item_num, dim, comm, backend_factory, device="cpu", slack=1.25):
         self.U, self.I, self.D = int(user_num), int(item_num), int(dim)
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
@@ -236,7 +236,7 @@ class ShardedSvd(object):
             sample_cap = max(1, Bg)
             return sample_cap, max(1, min(self.per_i, sample_cap))
         sample_cap = min(Bg, int(self.slack * Bg / W) + 4096)
-        return sample_cap, max(1, min(self.per_i, int(self.slack * Bg / (W * W)) + 1024))
+        return sample_cap, max(1, min(self.per_i, sample_cap, int(self.slack * Bg / (W * W)) + 1024))
 
     def _phase(self, name):
         if self.timers is None:
