@@ -110,6 +110,18 @@ int tfr_upload_eval_triples(tfr_model* m, const int32_t* user, const int32_t* it
                             int64_t n);
 int tfr_eval_resident(tfr_model* m, double* sum_sq_err_out, int64_t* n_equal_out, int64_t* n_out);
 
+/* the fork's epoch metrics on the device (svd_train_val.py:94-98,170-178: per-batch sklearn roc_auc_score and the fed-logits
+ * NLL are the host bottleneck SURVEY 8f #1 names): count of round(sigmoid(logit)) == rate, summed sigmoid cross-entropy
+ * (ops.py:125-126) and the AUC (rank sum over the radix-sorted logits, equal scores share their mean rank - what
+ * roc_auc_score computes; NaN when one class is empty).  Binary-outcome model (loss = nll) only. */
+int tfr_eval_binary(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate, int64_t batch,
+                    int64_t* n_equal_out, double* nll_sum_out, double* auc_out);
+int tfr_eval_binary_resident(tfr_model* m, int64_t* n_equal_out, double* nll_sum_out, double* auc_out, int64_t* n_out);
+/* roc_auc_score(rates, sigmoid(logits)) of the batch the last tfr_train_step ran on (svd_train_val.py:97) */
+int tfr_last_batch_auc(tfr_model* m, double* auc_out);
+/* roc_auc_score(label > 0.5, score) for device arrays */
+int tfr_auc_dev(tfr_model* m, const float* d_score, const float* d_label, int64_t n, double* auc_out);
+
 /* ---- one minibatch: sess.run([train_op, logits, infer], feed_dict) - svd_train_val.py:66-72;
  *      ops.py:81-89 (regulariser), ops.py:118-153 (loss, minimize).
  *      logits_out = pre-update logits of this batch; loss_out = data term only

@@ -247,3 +247,75 @@ def test_reference_spellings_run_after_the_import_swaps(tmp_path):
         summary_writer.close()
     lines = [json.loads(x) for x in open(logdir + "/events.jsonl")]
     assert [x["step"] for x in lines if x.get("tag") == "training_error"] == [0, 1, 2, 3]
+
+
+def test_fork_epoch_metrics_on_device():
+    """svd_train_val.py:94-98,170-178 computes, per batch on the host, round(sigmoid(logits)) == rates, the fed-logits NLL
+    and sklearn's roc_auc_score.  eval_binary gives the three from the device: the AUC is an exact integer rank sum over the
+    radix-sorted logits (ties share their mean rank), so against sklearn on the SAME logits it agrees to rounding."""
+    import torch
+    from sklearn.metrics import roc_auc_score
+    import tfrecomm_amd as T
+    U, I, D, B = 400, 300, 20, 30000
+    rs = np.random.RandomState(3)
+    t = rand_tables(rs, U, I, D)
+    u, i = rs.randint(0, U, B), rs.randint(0, I, B)
+    r = (rs.rand(B) < 0.4).astype(np.float32)
+    orc = make_oracle(U, I, D, t, loss="nll", item_abs=True, reg_bias=True, optimizer="sgd")
+    with T.SvdModel(U, I, D, loss="nll", item_abs=True, reg_bias=True, optimizer="sgd", device=0) as m:
+        m.set_tables(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        got = m.eval_binary(u, i, r)
+        lg = m.forward(u, i)
+        want_logits = orc.forward(u, i)
+        p = 1.0 / (1.0 + np.exp(-want_logits))
+        assert abs(got["acc"] - np.mean(np.round(p) == r)) <= 2.0 / B              # a logit within rounding of 0 may flip
+        nll = np.mean(np.maximum(want_logits, 0) - want_logits * r + np.log1p(np.exp(-np.abs(want_logits))))
+        assert abs(got["mean_nll"] - nll) <= 1e-5 * nll
+        assert abs(got["auc"] - roc_auc_score(r, lg.astype(np.float64))) <= 1e-12   # same logits: exact rank arithmetic
+        assert abs(got["auc"] - roc_auc_score(r, p)) <= 1e-6
+        # the resident validation set gives the same numbers
+        m.upload_eval_triples(u, i, r)
+        res = m.eval_binary_resident()
+        assert res["n"] == B and res["auc"] == got["auc"] and res["acc"] == got["acc"]
+        # heavy ties, both signs, zeros of both signs, one class empty
+        dev = torch.device("cuda", 0)
+        for n, levels in ((5000, 7), (100000, 3), (64, 64), (1, 1)):
+            sc = rs.randint(-levels, levels + 1, n).astype(np.float32) * np.float32(0.25)
+            sc[sc == 0] *= rs.choice([-1.0, 1.0], int((sc == 0).sum())).astype(np.float32)
+            lab = (rs.rand(n) < 0.3).astype(np.float32)
+            d_sc, d_lab = torch.from_numpy(sc).to(dev), torch.from_numpy(lab).to(dev)     # keep both alive across the call
+            torch.cuda.synchronize()
+            a = m.auc_dev(d_sc.data_ptr(), d_lab.data_ptr(), n)
+            if 0 < lab.sum() < n:
+                assert abs(a - roc_auc_score(lab, sc.astype(np.float64))) <= 1e-12, (n, levels)
+            else:
+                assert np.isnan(a)
+    with T.SvdModel(U, I, D, device=0) as m2:                    # the canonical (mse) model has no such metrics
+        with pytest.raises(T.TfrError):
+            m2.eval_binary(u, i, r)
+
+
+def test_discrete_driver_logs_the_forks_epoch_line():
+    """svd(discrete=True): the fork's `TRAIN(size, macc, mauc, mnll) TEST(size, macc, auc, mnll)` line (svd_train_val.py:170-178),
+    AUC / NLL / accuracy from the device; the printed test AUC equals sklearn's on the model's own logits."""
+    import re
+    from sklearn.metrics import roc_auc_score
+    rs = np.random.RandomState(9)
+    U, I, n = 200, 150, 6000
+    pu, qi = rs.normal(0, 1, (U, 4)), rs.normal(0, 1, (I, 4))
+    u, i = rs.randint(0, U, n).astype(np.int32), rs.randint(0, I, n).astype(np.int32)
+    y = (rs.rand(n) < 1 / (1 + np.exp(-(pu[u] * np.abs(qi[i])).sum(1)))).astype(np.float32)
+    mk = lambda s: {"user": u[s], "item": i[s], "outcome": y[s]}
+    train, val = mk(slice(0, 5000)), mk(slice(5000, n))
+    lines = []
+    np.random.seed(13575)
+    rows = svd_train_val.svd(train, val, user_num=U, item_num=I, dim=8, batch_size=500, epoch_max=4, learning_rate=0.05,
+                             reg=0.001, discrete=True, log=lines.append)
+    ep = [l for l in lines if "TRAIN(" in l]
+    assert len(ep) == len(rows) == 4
+    m = re.search(r"TRAIN\(size=500/5000, macc=([\d.]+), mauc=([\d.]+), mnll=([\d.]+)\) TEST\(size=1000, macc=([\d.]+), auc=([\d.]+), mnll=([\d.]+)\)", ep[-1])
+    assert m, ep[-1]
+    tr_acc, tr_auc, tr_nll, te_acc, te_auc, te_nll = map(float, m.groups())
+    assert 0.5 < tr_auc <= 1.0 and 0.5 < te_auc <= 1.0 and 0 < tr_nll < 10 and 0 < te_nll < 10
+    first = re.search(r"TEST\(size=1000, macc=([\d.]+), auc=([\d.]+), mnll=([\d.]+)\)", ep[0])
+    assert te_auc > float(first.group(2))                       # it learns to rank (sum-loss SGD at this rate does not calibrate)

@@ -65,6 +65,10 @@ SIGNATURES = {
     "tfr_eval": (C.c_int, [_p, _i32p, _i32p, _f32p, C.c_int64, C.POINTER(C.c_double), _i64p]),
     "tfr_upload_eval_triples": (C.c_int, [_p, _i32p, _i32p, _f32p, C.c_int64]),
     "tfr_eval_resident": (C.c_int, [_p, C.POINTER(C.c_double), _i64p, _i64p]),
+    "tfr_eval_binary": (C.c_int, [_p, _i32p, _i32p, _f32p, C.c_int64, _i64p, _f64p, _f64p]),
+    "tfr_eval_binary_resident": (C.c_int, [_p, _i64p, _f64p, _f64p, _i64p]),
+    "tfr_auc_dev": (C.c_int, [_p, _p, _p, C.c_int64, _f64p]),
+    "tfr_last_batch_auc": (C.c_int, [_p, _f64p]),
     "tfr_train_step": (C.c_int, [_p, _i32p, _i32p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
     "tfr_upload_triples": (C.c_int, [_p, _i32p, _i32p, _f32p, C.c_int64]),
     "tfr_train_steps_resident": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, _f32p]),

@@ -70,6 +70,8 @@ struct tfr_model {
     float* step_out = nullptr;        // per-step {loss, reg, sum_g} ring for multi-step calls
     int64_t step_out_cap = 0;
     int32_t* d_err = nullptr;
+    unsigned long long* d_auc = nullptr;   // {2 x rank sum of the positives, number of positives}
+    const float* last_r = nullptr; int64_t last_B = 0;     // rates of the last host-fed training batch whose logits were kept
     // host-fed calls (tfr_train_step / tfr_forward): one pinned staging buffer each way, so a step is one
     // H2D copy, the kernels and one D2H copy instead of five pageable transfers
     int32_t* d_in = nullptr; int32_t* h_in = nullptr; float* h_out = nullptr; int64_t stage_cap = 0;
@@ -332,7 +334,7 @@ int tfr_destroy(tfr_model* m) {
     free_workspace(m);
     for (int t = 0; t < 5; ++t) { dfree(m->w[t]); dfree(m->m[t]); dfree(m->v[t]); }
     dfree(m->map_u); dfree(m->map_i); dfree(m->dg_p); dfree(m->dg_q); dfree(m->dg_bu); dfree(m->dg_bi); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
-    dfree(m->store);
+    dfree(m->store); dfree(m->d_auc);
     dfree(m->d_ids); dfree(m->ev_u); dfree(m->ev_i); dfree(m->ev_r);
     if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); }
     if (m->stream3) { (void)hipStreamSynchronize(m->stream3); (void)hipStreamDestroy(m->stream3); }
@@ -1094,21 +1096,49 @@ int tfr_forward(tfr_model* m, const int32_t* u, const int32_t* i, int64_t B, flo
     return check_device_error(m);
 }
 
+// rank-sum AUC of n device scores against device labels (> 0.5 = positive); NaN when a class is empty
+static int auc_device(tfr_model* m, const float* d_score, const float* d_label, int64_t n, double* auc_out) {
+    int rc;
+    if ((rc = ensure_capacity(m, n))) return rc;
+    if (!m->d_auc) { if ((rc = dmalloc(&m->d_auc, 2))) return rc; }
+    hipStream_t s = m->stream;
+    HIPCHK(hipMemsetAsync(m->d_auc, 0, 16, s));
+    launch_auc_keys(d_score, m->d_i, n, s);              // d_i: batch-sized int scratch
+    HIPCHK(hipGetLastError());
+    const int32_t* keys[2] = {m->d_i, nullptr};
+    const int bits[2] = {32, 0};
+    int32_t* ks[2] = {m->ks_i, nullptr};
+    int32_t* ps[2] = {m->ps_i, nullptr};
+    if ((rc = radix_sort_columns(m, 1, keys, bits, ks, ps, n))) return rc;
+    launch_auc_ranksum(m->ks_i, m->ps_i, d_label, n, m->d_auc, s);
+    HIPCHK(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, m->d_auc, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const double np = (double)h[1], nn = (double)n - np;
+    if (auc_out) *auc_out = (np > 0 && nn > 0) ? (0.5 * (double)h[0] - 0.5 * np * (np + 1.0)) / (np * nn) : NAN;
+    return TFR_OK;
+}
+
 static int eval_device(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
-                       double* sse_out, int64_t* neq_out) {
+                       double* sse_out, int64_t* neq_out, double* nll_out = nullptr, double* auc_out = nullptr) {
     int nblk = 0, rc;
-    if ((rc = run_forward(m, MODE_EVAL, du, di, dr, B, nullptr, nullptr, &nblk))) return rc;
+    if (auc_out && (rc = ensure_capacity(m, B))) return rc;
+    if ((rc = run_forward(m, MODE_EVAL, du, di, dr, B, auc_out ? m->d_logits : nullptr, nullptr, &nblk))) return rc;
     std::vector<float> part((size_t)nblk * 4);
     HIPCHK(hipMemcpyAsync(part.data(), m->partials, part.size() * 4, hipMemcpyDeviceToHost, m->stream));
     if ((rc = check_device_error(m))) return rc;
-    double sse = 0.0;
+    double sse = 0.0, nll = 0.0;
     int64_t neq = 0;
     for (int b = 0; b < nblk; ++b) {
         sse += (double)part[(size_t)b * 4 + 0];
         neq += (int64_t)llround((double)part[(size_t)b * 4 + 1]);
+        nll += (double)part[(size_t)b * 4 + 2];
     }
     if (sse_out) *sse_out = sse;
     if (neq_out) *neq_out = neq;
+    if (nll_out) *nll_out = nll;
+    if (auc_out) return auc_device(m, m->d_logits, dr, B, auc_out);
     return TFR_OK;
 }
 
@@ -1147,6 +1177,42 @@ int tfr_upload_eval_triples(tfr_model* m, const int32_t* u, const int32_t* i, co
     return TFR_OK;
 }
 
+/* the fork's epoch line on the device (svd_train_val.py:94-98,170-178): accuracy count, summed sigmoid
+ * cross-entropy and AUC of the given batch / the resident validation set */
+int tfr_eval_binary(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t B,
+                    int64_t* neq_out, double* nll_sum_out, double* auc_out) {
+    MODEL_ENTER(m);
+    int rc = check_batch(u, i, B);
+    if (rc) return rc;
+    if (neq_out) *neq_out = 0;
+    if (nll_sum_out) *nll_sum_out = 0.0;
+    if (auc_out) *auc_out = NAN;
+    if (B == 0) return TFR_OK;
+    if (!r) return fail(TFR_ERR_ARG, "null rate pointer");
+    if (m->o.loss != TFR_LOSS_NLL) return fail(TFR_ERR_STATE, "eval_binary needs the binary-outcome model (loss = nll)");
+    if ((rc = ensure_capacity(m, B))) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_r, r, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    // (the AUC reuses d_i as key scratch - after the forward, in stream order, has read the ids)
+    return eval_device(m, m->d_u, m->d_i, m->d_r, B, nullptr, neq_out, nll_sum_out, auc_out);
+}
+
+int tfr_eval_binary_resident(tfr_model* m, int64_t* neq_out, double* nll_sum_out, double* auc_out, int64_t* n_out) {
+    MODEL_ENTER(m);
+    if (!m->ev_n) return fail(TFR_ERR_STATE, "no resident validation set: call tfr_upload_eval_triples first");
+    if (m->o.loss != TFR_LOSS_NLL) return fail(TFR_ERR_STATE, "eval_binary needs the binary-outcome model (loss = nll)");
+    if (n_out) *n_out = m->ev_n;
+    return eval_device(m, m->ev_u, m->ev_i, m->ev_r, m->ev_n, nullptr, neq_out, nll_sum_out, auc_out);
+}
+
+/* AUC of arbitrary device scores / labels (label > 0.5 = positive): roc_auc_score on the device */
+int tfr_auc_dev(tfr_model* m, const float* d_score, const float* d_label, int64_t n, double* auc_out) {
+    MODEL_ENTER(m);
+    if (n < 1 || !d_score || !d_label || !auc_out) return fail(TFR_ERR_ARG, "auc_dev: bad arguments");
+    return auc_device(m, d_score, d_label, n, auc_out);
+}
+
 int tfr_eval_resident(tfr_model* m, double* sse_out, int64_t* neq_out, int64_t* n_out) {
     MODEL_ENTER(m);
     if (!m->ev_n) return fail(TFR_ERR_STATE, "no resident validation set: call tfr_upload_eval_triples first");
@@ -1175,6 +1241,7 @@ int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float
     const int64_t step0 = m->step;
     const float b1p0 = m->b1p, b2p0 = m->b2p;
     float sc[4] = {0.f, 0.f, 0.f, 0.f};
+    m->last_r = nullptr;
     if (B > 0 && B <= STAGE_MAX) {
         // one pinned H2D copy in, the kernels, one D2H copy out: [logits | loss, reg, sum g, error flag]
         if ((rc = ensure_staging(m, B))) return rc;
@@ -1195,6 +1262,7 @@ int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float
         }
         if (logits_out) memcpy(logits_out, m->h_out, (size_t)B * 4);
         sc[0] = m->h_out[nl]; sc[1] = m->h_out[nl + 1];
+        m->last_r = logits_out ? reinterpret_cast<const float*>(m->d_in + 2 * B) : nullptr; m->last_B = B;
     } else {
         if (B > 0) {
             HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
@@ -1214,6 +1282,15 @@ int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float
     if (loss_out) *loss_out = sc[0];
     if (reg_out) *reg_out = sc[1];
     return TFR_OK;
+}
+
+/* roc_auc_score(rates, sigmoid(logits)) of the batch the last tfr_train_step ran on (its pre-update logits, the ones
+ * the caller was handed): svd_train_val.py:97, without sklearn on the host.  Needs that call to have asked for logits. */
+int tfr_last_batch_auc(tfr_model* m, double* auc_out) {
+    MODEL_ENTER(m);
+    if (!auc_out) return fail(TFR_ERR_ARG, "null output");
+    if (!m->last_r || m->last_B < 1) return fail(TFR_ERR_STATE, "no kept batch: call tfr_train_step with logits_out first (batches up to 2^20)");
+    return auc_device(m, m->d_logits, m->last_r, m->last_B, auc_out);
 }
 
 // ---- resident store --------------------------------------------------------------------

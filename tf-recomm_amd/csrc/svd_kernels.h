@@ -216,6 +216,8 @@ void launch_gather(const GatherArgs& a, hipStream_t s);
 void launch_gather_rows(const GatherRowsArgs& a, int G, int VEC, hipStream_t s);
 void launch_pack_triples(const int32_t* u, const int32_t* it, const float* r, void* store, int64_t n, hipStream_t s);
 void launch_finalize(const FinArgs& a, hipStream_t s);
+void launch_auc_keys(const float* score, int32_t* keys, int64_t n, hipStream_t s);
+void launch_auc_ranksum(const int32_t* ks, const int32_t* ps, const float* label, int64_t n, unsigned long long* out, hipStream_t s);
 void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, hipStream_t s);
 void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s);
 

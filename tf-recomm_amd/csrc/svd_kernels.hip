@@ -333,6 +333,9 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
                     const float d = inf - r;
                     acc[0] += d * d;
                     acc[1] += (inf == r) ? 1.f : 0.f;
+                    // svd_train_val.py:94,170-178: the epoch line's mean NLL (ops.py:125-126 on the fed logits)
+                    if (a.loss != 0) acc[2] += fmaxf(logit, 0.f) - logit * r + log1pf(__expf(-fabsf(logit)));
+                    if (a.logits) a.logits[k[j]] = logit;                // kept for the AUC (rank sum over the sorted logits)
                 }
             }
             if constexpr (MODE == MODE_TRAIN) {
@@ -1384,6 +1387,50 @@ __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
 }
 
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a) { finalize_body(a); }
+
+// ------------------------------------------------------------------------------------
+// AUC on the device (svd_train_val.py:97,173: sklearn's roc_auc_score(rates, sigmoid(logits)) per batch is the host
+// bottleneck SURVEY 8f #1 names).  AUC = (sum of the positives' mid-ranks - n_pos (n_pos + 1) / 2) / (n_pos n_neg)
+// (Mann-Whitney; equal scores share the mean of their ranks, which is what the ROC trapezoids give).  Scores are
+// mapped to 32-bit keys in score order, sorted by the library's radix sort, and every positive finds how many keys
+// are smaller / not larger than its own by two binary searches of the sorted keys; twice the mid-rank is the
+// integer lo + hi + 1, so the rank sum is exact integer arithmetic (64-bit integer adds: order-independent).
+__global__ __launch_bounds__(256) void k_auc_keys(const float* __restrict__ score, int32_t* __restrict__ keys, int64_t n) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        float x = score[k];
+        if (x == 0.f) x = 0.f;                           // -0 and +0 are equal scores
+        const uint32_t b = __float_as_uint(x);
+        keys[k] = (int32_t)((b & 0x80000000u) ? ~b : (b | 0x80000000u));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_auc_ranksum(const int32_t* __restrict__ ks, const int32_t* __restrict__ ps,
+                                                     const float* __restrict__ label, int64_t n, unsigned long long* out /* {2 x rank sum, n_pos} */) {
+    unsigned long long s2 = 0, np = 0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        if (label[ps[j]] > 0.5f) {
+            const uint32_t key = (uint32_t)ks[j];
+            int64_t lo = 0, hi = n;                      // first index with a key >= mine
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint32_t)ks[mid] < key) lo = mid + 1; else hi = mid; }
+            const int64_t first = lo;
+            hi = n;                                      // first index with a key > mine
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint32_t)ks[mid] <= key) lo = mid + 1; else hi = mid; }
+            s2 += (unsigned long long)(first + lo + 1);  // 1-based ranks first+1 .. lo: twice their mean
+            np += 1;
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) { s2 += __shfl_down(s2, o, 64); np += __shfl_down(np, o, 64); }
+    if ((threadIdx.x & 63) == 0 && np) { atomicAdd(&out[0], s2); atomicAdd(&out[1], np); }
+}
+
+void launch_auc_keys(const float* score, int32_t* keys, int64_t n, hipStream_t s) {
+    int64_t nb = (n + 255) / 256; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_auc_keys, dim3((int)nb), dim3(256), 0, s, score, keys, n);
+}
+void launch_auc_ranksum(const int32_t* ks, const int32_t* ps, const float* label, int64_t n, unsigned long long* out, hipStream_t s) {
+    int64_t nb = (n + 255) / 256; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_auc_ranksum, dim3((int)nb), dim3(256), 0, s, ks, ps, label, n, out);
+}
 
 // ------------------------------------------------------------------------------------
 // Variable initialisers (ops.py:8-12,29-32): truncated normal = N(0, s) resampled until

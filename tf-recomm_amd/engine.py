@@ -133,6 +133,33 @@ class SvdModel:
         L.check(self._lib.tfr_eval_resident(self._h, C.byref(sse), C.byref(neq), C.byref(n)))
         return sse.value, neq.value, n.value
 
+    def eval_binary(self, users, items, rates):
+        """The fork's epoch metrics on the device (svd_train_val.py:94-98,170-178): dict(acc, mean_nll, auc, n)."""
+        u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
+        if not (u.shape == i.shape == r.shape) or u.ndim != 1:
+            raise ValueError("batches must be 1-D and of equal length")
+        neq, nll, auc = C.c_int64(), C.c_double(), C.c_double()
+        L.check(self._lib.tfr_eval_binary(self._h, L.ptr_i32(u), L.ptr_i32(i), L.ptr_f32(r), u.size,
+                                          C.byref(neq), C.byref(nll), C.byref(auc)))
+        n = max(1, u.size)
+        return dict(acc=neq.value / n, mean_nll=nll.value / n, auc=auc.value, n=u.size)
+
+    def eval_binary_resident(self):
+        neq, nll, auc, n = C.c_int64(), C.c_double(), C.c_double(), C.c_int64()
+        L.check(self._lib.tfr_eval_binary_resident(self._h, C.byref(neq), C.byref(nll), C.byref(auc), C.byref(n)))
+        return dict(acc=neq.value / max(1, n.value), mean_nll=nll.value / max(1, n.value), auc=auc.value, n=n.value)
+
+    def last_batch_auc(self):
+        """AUC of the batch the last ``train_step`` (with logits) ran on - svd_train_val.py:97 on the device."""
+        auc = C.c_double()
+        L.check(self._lib.tfr_last_batch_auc(self._h, C.byref(auc)))
+        return auc.value
+
+    def auc_dev(self, d_score, d_label, n):
+        auc = C.c_double()
+        L.check(self._lib.tfr_auc_dev(self._h, d_score, d_label, int(n), C.byref(auc)))
+        return auc.value
+
     def train_step(self, users, items, rates, want_logits=True):
         u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
         if not (u.shape == i.shape == r.shape) or u.ndim != 1:

@@ -59,14 +59,18 @@ def svd(train, test, *, user_num=None, item_num=None, dim=None, batch_size=None,
         log("{} {} {} {}".format("epoch", "train_error", "val_error", "elapsed_time"))
         train_se = deque(maxlen=nb_batches)                             # :59
         train_acc = deque(maxlen=nb_batches)
+        train_auc = deque(maxlen=nb_batches)                            # :61-64 (fork): per-batch AUC and NLL
+        train_nll = deque(maxlen=nb_batches)
         start = time.time()
         for i in range(epoch_max * nb_batches):                         # :66
             train_users, train_items, train_rates = next(iter_train)
-            _, train_logits, train_infer = sess.run(
-                [train_op, logits, infer],
+            _, train_logits, train_infer, nll_batch = sess.run(
+                [train_op, logits, infer, cost],
                 feed_dict={user_batch: train_users, item_batch: train_items, rate_batch: train_rates})
             if discrete:
                 train_acc.append(np.round(ops.sigmoid(train_logits)) == train_rates)      # :96
+                train_auc.append(sess.model.last_batch_auc())           # :97 roc_auc_score, on the device
+                train_nll.append(nll_batch)                             # :94,98 (the cost of this very run)
             else:
                 train_se.append(np.power(train_rates - train_infer, 2))                   # :104
             if i % nb_batches == 0:                                     # :106 (also at i=0, after ONE step)
@@ -83,7 +87,13 @@ def svd(train, test, *, user_num=None, item_num=None, dim=None, batch_size=None,
                 test_err = np.mean(test_acc) if discrete else np.sqrt(np.mean(test_se))   # :149
                 row = (i // nb_batches, float(train_err), float(test_err), end - start)
                 rows.append(row)
-                log("{:3d} {:f} {:f} {:f}(s)".format(*row))             # README.md:49-57
+                if discrete:                                            # :170-178: the fork's epoch line, metrics from the device
+                    tm = sess.model.eval_binary(test["user"], test["item"], test["outcome"])
+                    log("{:3d} TRAIN(size={:d}/{:d}, macc={:f}, mauc={:f}, mnll={:f}) TEST(size={:d}, macc={:f}, auc={:f}, mnll={:f}) {:f}(s)".format(
+                        i // nb_batches, len(train_users), len(train["user"]), float(train_err), float(np.mean(train_auc)),
+                        float(np.mean(train_nll)) / batch_size, tm["n"], tm["acc"], tm["auc"], tm["mean_nll"], end - start))
+                else:
+                    log("{:3d} {:f} {:f} {:f}(s)".format(*row))         # README.md:49-57
                 start = end
         if save_path:
             log(saver.save(sess, save_path))                            # :197-198
