@@ -617,7 +617,7 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
 // sorted keys in ks_out[c], original positions in ps_out[c].  ceil(maxbits/8) passes, 3 launches each.
 static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* keys, const int* bits,
                               int32_t* const* ks_out, int32_t* const* ps_out, int64_t B,
-                              const int64_t* limits = nullptr) {
+                              const int64_t* limits = nullptr, const int64_t* store_ids = nullptr) {
     int maxbits = bits[0];
     if (ncols > 1 && bits[1] > maxbits) maxbits = bits[1];
     const int passes = (maxbits + 7) / 8;
@@ -643,6 +643,11 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
             r.vals_out[c] = to_final ? ps_out[c] : tmpv[c];
         }
         r.shift = 8 * p;
+        r.ids = nullptr;
+        if (p == 0 && store_ids) {                               // the first pass gathers the batch from the resident store itself
+            r.ids = store_ids; r.store = m->store; r.N = m->N;
+            r.u_out = m->d_u; r.i_out = m->d_i; r.r_out = m->d_r;
+        }
         r.err = (p == 0 && limits) ? m->d_err : nullptr;         // ids outside the tables void the step
         if (limits) for (int c = 0; c < ncols; ++c) r.limit[c] = (int32_t)limits[c];
         launch_rsort_pass(r, ncols, m->stream);
@@ -653,7 +658,8 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
 
 // stable sort of batch positions by user id and by item id
 static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int64_t B,
-                        const FinArgs* fin = nullptr, bool* fin_done = nullptr, bool validate = false) {
+                        const FinArgs* fin = nullptr, bool* fin_done = nullptr, bool validate = false,
+                        const int64_t* store_ids = nullptr) {
     Prof p(m, TFR_K_SORT);
     if (m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i)) {
         CSortArgs c;
@@ -675,7 +681,7 @@ static int sort_columns(tfr_model* m, const int32_t* du, const int32_t* di, int6
     int32_t* ks[2] = {m->ks_u, m->ks_i};
     int32_t* ps[2] = {m->ps_u, m->ps_i};
     const int64_t limits[2] = {m->U, m->I};
-    return radix_sort_columns(m, 2, keys, bits, ks, ps, B, validate ? limits : nullptr);
+    return radix_sort_columns(m, 2, keys, bits, ks, ps, B, validate ? limits : nullptr, store_ids);
 }
 
 // big tables with a touched-rows optimiser: the forward is computed inside the item-side reduce,
@@ -701,6 +707,13 @@ static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, 
     hipStream_t s = m->stream;
     int rc;
     if (sort_only) {
+        const bool radix = !(m->csort_ok && csort_eligible(B, m->bits_u, m->bits_i));
+        static int fuse = -1;                            // TFR_FUSE_GATHER=0: A/B switch (separate k_gather_triples launch)
+        if (fuse < 0) { const char* e = getenv("TFR_FUSE_GATHER"); fuse = (e && e[0] == '0') ? 0 : 1; }
+        if (d_store_ids && radix && fuse) {                      // the radix sort's first pass gathers the batch itself (one launch less)
+            du = m->d_u; di = m->d_i; dr = m->d_r;
+            return sort_columns(m, du, di, B, nullptr, nullptr, true, d_store_ids);
+        }
         if (d_store_ids) {
             if ((rc = gather_batch(m, d_store_ids, 0, B))) return rc;
             du = m->d_u; di = m->d_i; dr = m->d_r;
@@ -1802,7 +1815,7 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
                  tile_step_epg((int)ntiles, G, V), G, V, nt);
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
-        snprintf(tmp, sizeof(tmp), "gather=k_gather_triples;sort=k_rsort_rank/scan/scatter x%d passes;reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
+        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
                  "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>;finalize=k_finalize",
                  ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
     } else if (csort) {

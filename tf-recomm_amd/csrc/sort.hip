@@ -176,7 +176,18 @@ __global__ __launch_bounds__(CSORT_TILE) void k_rsort_rank(RSortArgs a) {
     __syncthreads();
     const int64_t k = (int64_t)tile * CSORT_TILE + tid;
     const bool valid = k < a.B;
-    const int32_t key = valid ? a.keys_in[col][k] : 0;
+    int32_t key = 0;
+    if (valid) {
+        if (a.ids) {                                     // fused gather: this pass reads the store records itself
+            int64_t id = a.ids[k];
+            if ((uint64_t)id >= (uint64_t)a.N) { if (a.err) atomicOr(a.err, 2); id = 0; }
+            const int4 rec = a.store[id];
+            key = col == 0 ? rec.x : rec.y;
+            if (col == 0) { a.u_out[k] = rec.x; a.i_out[k] = rec.y; a.r_out[k] = __int_as_float(rec.z); }
+        } else {
+            key = a.keys_in[col][k];
+        }
+    }
     const int32_t digit = (key >> a.shift) & 255;
     if (a.err && a.shift == 0) {                         // range check rides in the first pass
         const bool bad = valid && (uint32_t)key >= (uint32_t)a.limit[col];

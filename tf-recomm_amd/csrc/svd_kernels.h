@@ -264,6 +264,9 @@ struct RSortArgs {
     int32_t shift, ntiles, chunk;                            // chunk: multiple of 1024, <= 16384
     int64_t B;
     int32_t limit[2]; int32_t* err;                          // err != NULL: pass 0 flags keys outside [0, limit)
+    // pass 0 may gather the batch itself (dataio.py:115-117 on the resident store): key = store[ids[k]].x / .y; the column-0
+    // blocks also write the gathered (user, item, rate) to keys_in[0], keys_in[1] (non-const alias) and r_out for the later passes
+    const int64_t* ids; const int4* store; int64_t N; float* r_out; int32_t* u_out; int32_t* i_out;
 };
 void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s);
 
