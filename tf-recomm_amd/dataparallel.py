@@ -155,7 +155,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
                             parallelism="dp%d: replicated tables, one %.1f MB gradient all-reduce (RCCL) per step"
                                         % (world, nbytes / 1e6)),
                 val_rmse=float(np.sqrt(sse / len(val[0]))),
-                roofline=dict(kernel="all_reduce (RCCL over xGMI)", bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
+                roofline=dict(kernel="all_reduce (%s)" % ("gloo rehearsal: staged through host memory, times meaningless" if stage else "RCCL over xGMI"), bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
                               frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire, phases_us=phases,
                               note="bytes each rank sends per step, 2 (N-1)/N x the %.1f MB gradient buffer, over the whole step time; the "
                                    "2.6 MB model makes this step latency-bound (collective launch + a few link hops), not bandwidth-bound; "

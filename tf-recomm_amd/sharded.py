@@ -371,7 +371,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
                             optimizer="adam", adam_mode=wl["adam_mode"], sample_cap=sample_cap, slot_cap=slot_cap,
                             parallelism="row-sharded tables x%d: device-side routing, 3 equal-split all-to-alls (request slots, "
                                         "packed rows, packed gradient rows) + one 16-byte all-reduce per step over RCCL, no host sync" % world),
-                roofline=dict(kernel="all_to_all (RCCL over xGMI)", bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
+                roofline=dict(kernel="all_to_all (%s)" % ("gloo rehearsal: staged through host memory, times meaningless" if comm.stage else "RCCL over xGMI"), bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
                               frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire,
                               exchange_us_per_step=exch_us, phases_us=phases,
                               note="egress bytes per rank and step (fixed-capacity slots: %d of them to each of %d peers, %d B each way per slot) "
