@@ -103,9 +103,11 @@ def svd(train, test, *, user_num=None, item_num=None, dim=None, batch_size=None,
 def svd_resident(train, test, *, user_num=None, item_num=None, dim=None, batch_size=None, epoch_max=None,
                  learning_rate=None, reg=None, device=None, adam_mode="tf1", json_log=None, log=print):
     """The same run with every input resident in HBM: the rating store and the
-    validation set are uploaded once, the host only draws the reference's ``randint`` id stream,
-    one epoch of minibatches is one C-ABI call, and the validation error is reduced on the device.
-    Prints the README rows and (optionally) writes one JSON line per epoch with ratings/sec."""
+    validation set are uploaded once, the reference's ``randint`` id stream is drawn ON THE DEVICE (NumPy's
+    generator state goes there before an epoch and comes back after it, so host code that draws in between
+    sees one unbroken stream), one epoch of minibatches is one C-ABI call, and the validation error is
+    reduced on the device.  Prints the README rows and (optionally) writes one JSON line per epoch with
+    ratings/sec."""
     import json
     from .engine import SvdModel
     user_num, item_num = user_num or C.USER_NUM, item_num or C.ITEM_NUM
@@ -128,8 +130,9 @@ def svd_resident(train, test, *, user_num=None, item_num=None, dim=None, batch_s
             # epoch 0 of the reference is evaluated after ONE step (svd_train_val.py:106); later rows
             # after nb_batches more
             steps = 1 if epoch == 0 else nb_batches
-            ids = np.random.randint(0, n_train, (steps, batch_size))      # dataio.py:115, one draw per step
-            loss = m.train_steps_resident(ids, batch_size)                # data term 0.5*sum(err^2) per step
+            m.rng_from_numpy()                                            # dataio.py:115: randint(0, n_train, (batch,)) per step,
+            loss = m.train_steps_drawn(batch_size, steps, want_loss=True)  # drawn by the device; data term 0.5*sum(err^2) per step
+            m.rng_to_numpy()
             train_err = float(np.sqrt(2.0 * loss.astype(np.float64).sum() / (steps * batch_size)))
             sse, _, n = m.eval_resident()
             end = time.time()
