@@ -25,6 +25,8 @@
 // branches on the wave index, all LDS reads of a form issued together, one LDS round trip per block), the two waves
 // that straddle a form boundary use masked variants, the block's last word (five tw terms) is computed on the
 // lightest SIMD, and block k's ranking / stores overlap block k+2's regeneration (software pipeline).
+// Tried and dropped: the same generator on four waves (one per SIMD) with three words per thread, to pay the per-block fixed
+// costs four times instead of ten - 1800-1900 cycles per block against 1290-1630 here (one gpurun call, same box).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svd_kernels.h"
