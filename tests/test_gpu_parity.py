@@ -549,3 +549,47 @@ def test_config3_full_size_properties():
     assert np.array_equal(runs[0][2], runs[1][2])
     assert runs[0][3] == 7
     assert runs[0][1][-1] < runs[0][1][0] < runs[0][0][0]                 # repeated batch: loss falls
+
+
+# ------------------------------------------------------------------ BASELINE config 4's tables on ONE GPU
+def test_config4_tables_on_one_gpu_properties():
+    """100M users x 10M items, dim=128 with lazy Adam: 56 GB of tables + 113 GB of Adam state = 169 GB in HBM (a table +
+    state outgrows one 288 GB MI355X only past ~187M rows), initialised on the device.  Size-independent properties at
+    batch 262144: permutation equivariance of the forward, a bit-identical trajectory from the same seed, a falling loss on a
+    repeated batch, the device-drawn id stream == the host-drawn one, id validation at the far end of the tables."""
+    U, I, D, B = 100_000_000, 10_000_000, 128, 262144
+    rs = np.random.RandomState(44)
+    batches = [(rs.randint(0, U, B).astype(np.int32), rs.randint(0, I, B).astype(np.int32),
+                rs.randint(1, 6, B).astype(np.float32)) for _ in range(2)]
+    # the far end of both tables is reachable: the last rows take part
+    batches[0][0][:8], batches[0][1][:8] = U - 1 - np.arange(8), I - 1 - np.arange(8)
+    probe_u, probe_i = batches[0][0][:60000].copy(), batches[1][1][:60000].copy()
+    N = 3_000_000
+    su, si = rs.randint(0, U, N).astype(np.int32), rs.randint(0, I, N).astype(np.int32)
+    sr = rs.randint(1, 6, N).astype(np.float32)
+    with T.SvdModel(U, I, D, optimizer="adam", adam_mode="lazy", lr=5e-3, reg=0.02) as m:
+        runs = []
+        for rep in range(2):                             # the same handle re-initialised: 169 GB are allocated once
+            m.init_tables(seed=6)
+            if rep == 0:
+                a = m.forward(batches[0][0], batches[0][1])
+                perm = rs.permutation(B)
+                assert np.array_equal(a[perm], m.forward(batches[0][0][perm], batches[0][1][perm]))
+                assert np.isfinite(a).all() and a.std() > 0.5
+                with pytest.raises(IndexError):
+                    m.forward(np.array([U], np.int64), np.array([0], np.int64))
+            losses = [m.train_step(*b, want_logits=False)[1] for b in batches]
+            rep_losses = [m.train_step(*batches[0], want_logits=False)[1] for _ in range(3)]
+            # resident store: two steps on device-drawn ids (rep 0) / on the same ids drawn by NumPy (rep 1)
+            m.upload_triples(su, si, sr)
+            np.random.seed(13575)
+            if rep == 0:
+                m.rng_from_numpy()
+                drawn = m.train_steps_drawn(B, 2, want_loss=True)
+            else:
+                drawn = m.train_steps_resident(np.random.randint(0, N, (2, B)), B)
+            runs.append((losses, rep_losses, drawn.tolist(), m.forward(probe_u, probe_i), m.step))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    assert np.array_equal(runs[0][3], runs[1][3])
+    assert runs[0][4] == runs[1][4] == 7
+    assert runs[0][1][-1] < runs[0][1][0] < runs[0][0][0]                 # repeated batch: loss falls

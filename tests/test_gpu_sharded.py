@@ -225,3 +225,48 @@ def test_data_parallel_rejects_lazy_adam():
     with T.SvdModel(10, 10, 8, optimizer="adam", adam_mode="lazy") as m:
         with pytest.raises(T.TfrError):
             m.dp_apply(1)
+
+
+def _big_world1(rank, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        import tfrecomm_amd as T
+        from tfrecomm_amd import sharded, _lib as L
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        U, I, D, B = 2_000_000, 200_000, 128, 262144            # the slack-capacity regime (batch > 65536), radix paths
+        kw = dict(optimizer="adam", adam_mode="lazy", lr=2e-3, reg=0.03)
+        rs = np.random.RandomState(23)
+        batches = [(rs.randint(0, U, B).astype(np.int32), rs.randint(0, I, B).astype(np.int32),
+                    rs.randint(1, 6, B).astype(np.float32)) for _ in range(3)]
+        comm = sharded.Comm()
+        m = sharded.ShardedSvd(U, I, D, comm, lambda ur, ir, d: sharded.HipShard(ur, ir, d, 0, **kw), device=dev)
+        sample_cap, slot_cap = m.capacities(B)
+        assert sample_cap == B and slot_cap == min(I, B)        # world 1: everything is local, nothing may overflow
+        m.backend.model.init_tables(seed=9)
+        with T.SvdModel(U, I, D, **kw) as ref:
+            ref.init_tables(seed=9)                             # counter-based initialiser: the same tables
+            for s, (u, i, r) in enumerate(batches):
+                logits, mine, scal = m.train_step(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(r).to(dev))
+                torch.cuda.synchronize()
+                wl, wloss, wreg = ref.train_step(u, i, r)
+                n = int(m.backend.routed()["counts"][0].item())
+                assert n == B and np.array_equal(mine.cpu().numpy(), np.arange(B))
+                assert rel_err(logits.cpu().numpy(), wl) <= RTOL * (s + 1)
+                sc = scal.cpu().numpy()
+                assert abs(sc[0] - wloss) <= 2 * RTOL * abs(wloss) and abs(sc[1] - wreg) <= 2 * RTOL * abs(wreg)
+            m.backend.sync()
+            probe_u, probe_i = batches[0][0][:50000], batches[1][1][:50000]
+            a = m.backend.model.forward(probe_u, probe_i)
+            assert rel_err(a, ref.forward(probe_u, probe_i)) <= 4 * RTOL        # the touched rows moved the same way
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_sharded_step_at_scale_equals_the_fused_single_gpu_step():
+    """The row-sharded step (device routing in its slack-capacity regime, packed exchange buffers, dynamic counts) on a
+    262144-rating batch over 2M x 200k-row tables, world 1: same logits, loss, regulariser and updated rows as the fused
+    single-GPU step of the same model."""
+    mp.spawn(_big_world1, args=(_free_port(),), nprocs=1, join=True)
