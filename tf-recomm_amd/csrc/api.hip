@@ -985,6 +985,11 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             app.a[1].w = m->w[TFR_P]; app.a[1].m = m->m[TFR_P]; app.a[1].v = m->v[TFR_P];
             app.a[1].bias_w = m->w[TFR_BU]; app.a[1].bias_m = m->m[TFR_BU]; app.a[1].bias_v = m->v[TFR_BU];
             app.a[1].frozen_rows = ru.frozen_rows; app.a[1].frozen_bias = ru.frozen_bias;
+            if (!fin_done) {           // K4 rides in the same launch (one launch and ~6 us fewer per big-table step)
+                f.nblk = nblk;
+                app.f = f; app.with_fin = 1;
+                fin_done = true;
+            }
             {
                 Prof p(m, TFR_K_APPLY);
                 launch_apply_rows(app, 2, adam ? 0 : 1, m->G, m->VEC, s);
@@ -1816,7 +1821,7 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
         snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
-                 "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>;finalize=k_finalize",
+                 "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
                  ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
     } else if (csort) {
         snprintf(tmp, sizeof(tmp), "forward=k_front<%d, %d>;sort=k_csort_scan/scatter;reduce_item=k_seg_reduce<%d, %d, %d, false, true>;apply=%s",

@@ -81,7 +81,17 @@ struct ApplyArgs {
     const int32_t* dB;                             // row-sharded step: entries actually present (<= B)
     int32_t wstride, wbstride;                     // OPT 2 (emit reduced rows): output row / bias stride (0 = D / 1)
 };
-struct ApplyPair { ApplyArgs a[2]; };
+struct FinArgs {
+    const float* partials; int32_t nblk;
+    float* scalars; float* out;
+    float* mu; float* mu_m; float* mu_v; const int32_t* err;
+    int32_t update_mu, opt, clear_partials;        // clear_partials: zero partials[0..3] after use
+    int32_t out_err;                               // out[3] = the step's error flag (as a float)
+    float alpha, b1, b2, eps, lr;
+};
+
+// with_fin: one more block column carries K4 (the step's scalars + bias_global) in the same launch
+struct ApplyPair { ApplyArgs a[2]; FinArgs f = {}; int32_t with_fin = 0; };
 
 struct DenseArgs {
     int32_t* map; const int32_t* ks; const float* grad_rows; const float* grad_bias;
@@ -90,14 +100,6 @@ struct DenseArgs {
     const int32_t* err;
     int64_t rows, B;
     int32_t D, frozen_rows, frozen_bias, opt;    // opt: 0 Adam, 1 SGD
-    float alpha, b1, b2, eps, lr;
-};
-struct FinArgs {
-    const float* partials; int32_t nblk;
-    float* scalars; float* out;
-    float* mu; float* mu_m; float* mu_v; const int32_t* err;
-    int32_t update_mu, opt, clear_partials;        // clear_partials: zero partials[0..3] after use
-    int32_t out_err;                               // out[3] = the step's error flag (as a float)
     float alpha, b1, b2, eps, lr;
 };
 

@@ -1077,6 +1077,10 @@ __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_ro
 template <int G, int VEC, int OPT>
 __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
     constexpr int PIECE = 1024 / G;
+    if (pr.with_fin && blockIdx.x == gridDim.x - 1) {    // the extra block column: K4 (block-uniform branch)
+        if (blockIdx.y == 0) finalize_body(pr.f);
+        return;
+    }
     const ApplyArgs& a = pr.a[blockIdx.y];
     const int32_t err = *a.err;
     constexpr int GPB = 256 / G;
@@ -1606,7 +1610,7 @@ void launch_apply_rows(const ApplyPair& p, int n, int opt, int G, int VEC, hipSt
     bool all_split = p.a[0].only_split != 0;
     if (n > 1 && !p.a[1].only_split) all_split = false;
     if (all_split) B = (B + 1024 / G - 1) / (1024 / G);      // one lane group per piece boundary
-    const dim3 grid(entry_grid(B, G), n);
+    const dim3 grid(entry_grid(B, G) + (p.with_fin ? 1 : 0), n);
 #define TFR_APP_CASE(g, v)                                                                  \
     if (G == g && VEC == v) {                                                               \
         if (opt == 0) hipLaunchKernelGGL((k_apply_rows<g, v, 0>), grid, dim3(256), 0, s, p); \
