@@ -69,10 +69,15 @@ def synth_movielens(U, I, N, seed=13575):
     return (u[tr], i[tr], r[tr]), (u[va], i[va], r[va])
 
 
-def synth_uniform(U, I, N, seed=13575):
+def synth_uniform(U, I, N, seed=13575, zipf=0.0):
     rs = np.random.RandomState(seed)
     u = rs.randint(0, U, N).astype(np.int32)
-    i = rs.randint(0, I, N).astype(np.int32)
+    if zipf > 0:        # popularity-skewed items (reported separately): rank k ~ k^-a, rank -> random row
+        w = 1.0 / np.arange(1, I + 1, dtype=np.float64) ** zipf
+        cdf = np.cumsum(w / w.sum())
+        i = rs.permutation(I).astype(np.int32)[np.minimum(np.searchsorted(cdf, rs.random_sample(N)), I - 1)]
+    else:
+        i = rs.randint(0, I, N).astype(np.int32)
     r = rs.randint(1, 6, N).astype(np.float32)
     cut = N - min(N // 10, 1_000_000)
     return (u[:cut], i[:cut], r[:cut]), (u[cut:], i[cut:], r[cut:])
@@ -397,6 +402,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5", "als"])
     ap.add_argument("--adam-mode", default=None, choices=["tf1", "lazy"])
     ap.add_argument("--store-ratings", type=int, default=None, help="override the size of the rating store")
+    ap.add_argument("--zipf", type=float, default=0.0, help="c3/c4 training store: item ids ~ Zipf(a) instead of uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the fixed 30-epoch val-RMSE leg")
@@ -485,7 +491,7 @@ def main():
 
     # ---- data: synthetic store; the id stream is the reference's: np.random.seed(13575), one
     #      randint(0, N, (B,)) per step (svd_train_val.py:15, dataio.py:115) ---------------------------------
-    train, val = gen(U, I, wl["N"])
+    train, val = gen(U, I, wl["N"], zipf=args.zipf) if args.zipf > 0 and gen is synth_uniform else gen(U, I, wl["N"])
     ntrain = len(train[0])
     small = B <= 16384 and max(U, I) <= 16384                    # the tile path (k_tile_step + k_dense_tiles)
 
@@ -581,7 +587,7 @@ def main():
     out = dict(metric=metric, value=value,
                unit="ratings/s", n_gpus=1, steps=K, warmup=W, ms_per_step=ms_per_step, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=wl["name"], users=U, items=I, dim=D, batch=B, train_ratings=ntrain,
+               config=dict(workload=wl["name"] + (" [item ids ~ Zipf(%.2f)]" % args.zipf if args.zipf > 0 else ""), users=U, items=I, dim=D, batch=B, train_ratings=ntrain,
                            optimizer="adam", adam_mode=wl["adam_mode"], lr=wl["lr"], reg=wl["reg"],
                            id_stream="np.random.seed(13575); randint(0, N, (B,)) per step, drawn inside the timed loop",
                            parallelism="single GPU"),

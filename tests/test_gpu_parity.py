@@ -477,6 +477,48 @@ def test_random_shapes_two_steps(case):
                          what="table %s" % TABLE_NAMES[tid])
 
 
+@pytest.mark.parametrize("opt,mode,D", [("adam", "lazy", 128), ("sgd", "tf1", 128), ("adam", "lazy", 20)])
+def test_hot_rows_cut_into_hundreds_of_pieces(opt, mode, D):
+    """Big-table (radix sort, fused in-place) step with one item on half of the batch and one user on a third of it: the
+    hot runs are cut into several hundred block-sized pieces, finished by k_apply_rows' wide piece walk (popularity-skewed
+    data, SURVEY 8d's Zipf run)."""
+    U, I, B = 40000, 30000, 20000
+    rs = np.random.RandomState(77 + D)
+    t = rand_tables(rs, U, I, D, scale=0.3 / np.sqrt(max(D, 16) / 16))
+    kw = dict(loss="mse", item_abs=False, reg_bias=False, optimizer=opt, adam_mode=mode, lr=3e-3, reg=0.02)
+    orc = make_oracle(U, I, D, t, **kw)
+    with model_from(U, I, D, t, **kw) as m:
+        for s in range(2):
+            u = rs.randint(0, U, B).astype(np.int32)
+            i = rs.randint(0, I, B).astype(np.int32)
+            i[rs.rand(B) < 0.5] = 4242 + s
+            u[rs.rand(B) < 0.33] = 31000 - s
+            r = rs.randint(1, 6, B).astype(np.float32)
+            logits, lossv, regv = m.train_step(u, i, r)
+            wl, wloss, wreg = orc.train_step(u, i, r)
+            tol = 2 * RTOL * (s + 1)
+            assert_close(logits, wl, rtol=tol, what="logits")
+            assert_close(lossv, wloss, rtol=tol, what="loss")
+            assert_close(regv, wreg, rtol=tol, what="reg")
+        got = m.tables()
+        for tid in TIDS:
+            base = 2e-4 if opt == "adam" else 4 * RTOL           # as in the sweep above: fp32 sums of ~B/2 terms on the hot rows
+            assert_close(got[tid], orc.tables()[tid], rtol=base * np.sqrt(B / 2 / 64), what="table %s" % TABLE_NAMES[tid])
+    # the shared walk adds the lane groups' partial sums in group order: a second run gives the same bits
+    rs = np.random.RandomState(77 + D)
+    rand_tables(rs, U, I, D, scale=0.3 / np.sqrt(max(D, 16) / 16))
+    with model_from(U, I, D, t, **kw) as m2:
+        for s in range(2):
+            u = rs.randint(0, U, B).astype(np.int32)
+            i = rs.randint(0, I, B).astype(np.int32)
+            i[rs.rand(B) < 0.5] = 4242 + s
+            u[rs.rand(B) < 0.33] = 31000 - s
+            m2.train_step(u, i, rs.randint(1, 6, B).astype(np.float32))
+        again = m2.tables()
+    for tid in TIDS:
+        assert np.array_equal(got[tid], again[tid]), TABLE_NAMES[tid]
+
+
 # ------------------------------------------------------------------ full-size training step (C3-shaped)
 @pytest.mark.parametrize("opt,mode", [("adam", "lazy"), ("sgd", "tf1")])
 def test_train_step_large_against_compacted_oracle(opt, mode):

@@ -1028,8 +1028,41 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 
 // a run's reduced gradient = its pieces added in piece order (head piece first); pieces
 // start at the run head and at every multiple of PIECE (= the reduce kernel's block span).
-// Continuation pieces are probed and loaded eight at a time (independent loads), so a hot row
-// split into a handful of pieces costs two memory round trips, not one per piece.
+// Continuation pieces are probed and loaded N at a time (independent loads, added in the order walked), so a hot row
+// split into a handful of pieces costs two memory round trips, not one per piece.  `step` = distance between the
+// pieces this caller walks (PIECE for all of them, a multiple when several lane groups share a run).
+template <int VEC, int N>
+__device__ __forceinline__ bool add_pieces(Frag<VEC>& t, float& gb, const float* __restrict__ grad_rows,
+                                           const float* __restrict__ grad_bias, const int32_t* __restrict__ ks,
+                                           int64_t B, int64_t safe, int64_t p, int64_t step, int32_t row, int d0, int D) {
+    int32_t key[N];                                      // unconditional loads from in-bounds addresses: a load behind
+#pragma unroll                                           // `pp < B &&` is a branch and a full wait per probe
+    for (int q = 0; q < N; ++q) {
+        const int64_t pp = p + (int64_t)q * step;
+        key[q] = ks[pp < B ? pp : safe];
+    }
+    Frag<VEC> x[N];
+    float xb[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const int64_t pp = (p + (int64_t)q * step < B) ? p + (int64_t)q * step : safe;
+        x[q] = load_frag<VEC>(grad_rows + (size_t)pp * D, d0, D);
+        xb[q] = grad_bias[pp];
+    }
+    bool go = true;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        go = go && (p + (int64_t)q * step < B) && key[q] == row;     // pieces are contiguous: stop at the first miss
+        if (go) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t.v[e] += x[q].v[e];
+            gb += xb[q];
+        }
+    }
+    return go;
+}
+
+// the narrow walk (k_adam_dense, where registers decide the sweep's occupancy): eight pieces per round trip
 template <int VEC, int PIECE>
 __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_rows,
                                                const float* __restrict__ grad_bias,
@@ -1039,34 +1072,7 @@ __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_ro
     gb = grad_bias[j];
     int64_t p = (j / PIECE + 1) * PIECE;
     if (p >= B || ks[p] != row) return t;                // the common case: a single piece
-    for (;;) {
-        bool same[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int64_t pp = p + (int64_t)q * PIECE;
-            same[q] = (pp < B) && (ks[pp] == row);
-        }
-        Frag<VEC> x[8];
-        float xb[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int64_t pp = (p + (int64_t)q * PIECE < B) ? p + (int64_t)q * PIECE : j;   // safe address
-            x[q] = load_frag<VEC>(grad_rows + (size_t)pp * D, d0, D);
-            xb[q] = grad_bias[pp];
-        }
-        bool go = true;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            go = go && same[q];                          // pieces are contiguous: stop at the first miss
-            if (go) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) t.v[e] += x[q].v[e];
-                gb += xb[q];
-            }
-        }
-        if (!go) break;
-        p += 8 * (int64_t)PIECE;
-    }
+    while (add_pieces<VEC, 8>(t, gb, grad_rows, grad_bias, ks, B, j, p, PIECE, row, d0, D)) p += 8 * (int64_t)PIECE;
     return t;
 }
 
@@ -1074,66 +1080,114 @@ __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_ro
 // K5a  apply reduced gradients held in scratch to the touched rows only: lazy Adam or SGD
 //      (ops.py:143-149).  One lane group per sorted entry; only run heads work.
 //      only_split: finish the runs k_seg_reduce could not apply in place (cut in >1 piece).
+//      A hot row (popularity-skewed ids: under Zipf(1.05) items the top row of a 262144 batch is cut into ~800
+//      pieces) is shared by the block: the owner adds the head piece and the next eight as run_total does; if all
+//      eight belonged to the run, lane group g of the block adds pieces 9+g, 9+g+GPB, ... (16 in flight each) and the
+//      owner adds the GPB partial sums in group order - a fixed order, so results stay bit-identical run to run.
 template <int G, int VEC, int OPT>
 __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
     constexpr int PIECE = 1024 / G;
+    constexpr int GPB = 256 / G;
+    constexpr int CW = 16;                               // pieces in flight per lane group in the shared walk
     if (pr.with_fin && blockIdx.x == gridDim.x - 1) {    // the extra block column: K4 (block-uniform branch)
         if (blockIdx.y == 0) finalize_body(pr.f);
         return;
     }
+    __shared__ float s_part[256 * VEC];
+    __shared__ float s_partb[GPB];
+    __shared__ long long s_next[GPB];                    // a long run's next piece position, or -1
+    __shared__ int32_t s_row[GPB];
     const ApplyArgs& a = pr.a[blockIdx.y];
     const int32_t err = *a.err;
-    constexpr int GPB = 256 / G;
-    const int gl = threadIdx.x % G;
+    const int gl = threadIdx.x % G, grp = threadIdx.x / G;
     const int d0 = gl * VEC;
     const int D = a.D;
     const int64_t Bn = a.dB ? (int64_t)*a.dB : a.B;      // row-sharded step: the entry count lives on the device
-    int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G;
-    int32_t row;
+    int64_t j = (int64_t)blockIdx.x * GPB + grp;
+    int32_t row = 0;
+    bool own;                                            // this lane group finishes a run (no early exits: barriers below)
     if (a.only_split) {
         // one lane group per piece boundary p: a run is split iff it crosses one.  The first
         // boundary a run crosses owns it; its head then lies in the PIECE entries before p.
         const int64_t p = (j + 1) * PIECE;
-        if (err || p >= Bn) return;
-        row = a.ks[p];
-        if (a.ks[p - 1] != row) return;                  // no run crosses this boundary
-        const int64_t lo = p - PIECE;
-        if (lo > 0 && a.ks[lo - 1] == row) return;       // crossed an earlier boundary: handled there
-        const int sh = ((threadIdx.x % 64) / G) * G;     // this group's lanes within the wave
-        j = p - 1;
-        for (int k = 0; k < PIECE; k += G) {             // sorted keys: the matches are a suffix of [lo, p)
-            const bool hit = (k + gl < PIECE) && a.ks[lo + k + gl] == row;
-            unsigned long long bits = __ballot(hit) >> sh;
-            if constexpr (G < 64) bits &= (1ull << G) - 1ull;
-            if (bits) { j = lo + k + (__ffsll((long long)bits) - 1); break; }
+        own = !err && p < Bn;
+        if (own) {
+            row = a.ks[p];
+            const int64_t lo = p - PIECE;
+            own = a.ks[p - 1] == row && !(lo > 0 && a.ks[lo - 1] == row);   // crossed here, and not an earlier boundary
+            if (own) {
+                const int sh = ((threadIdx.x % 64) / G) * G;     // this group's lanes within the wave
+                j = p - 1;
+                for (int k = 0; k < PIECE; k += G) {             // sorted keys: the matches are a suffix of [lo, p)
+                    const bool hit = (k + gl < PIECE) && a.ks[lo + k + gl] == row;
+                    unsigned long long bits = __ballot(hit) >> sh;
+                    if constexpr (G < 64) bits &= (1ull << G) - 1ull;
+                    if (bits) { j = lo + k + (__ffsll((long long)bits) - 1); break; }
+                }
+            }
         }
     } else {
-        if (j >= Bn) return;
-        row = a.ks[j];
-        const int32_t prev = (j > 0) ? a.ks[j - 1] : -2;
-        if (err || prev == row) return;                  // voided step / not a run head
-    }
-    const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
-    const size_t roff = (size_t)row * D;
-    Frag<VEC> w, mrow, vrow;
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
-    if constexpr (OPT == 2) {                            // sharded step: emit the reduced gradient row
-        float gb2;
-        const Frag<VEC> tot = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, Bn, j, row, d0, D, gb2);
-        store_frag<VEC>(a.w + (a.wstride ? (size_t)row * a.wstride : roff), d0, D, tot);
-        if (gl == 0) a.bias_w[a.wbstride ? (size_t)row * a.wbstride : (size_t)row] = gb2;
-        return;
-    }
-    if (!a.frozen_rows) {                                // issued before the piece walk
-        w = load_frag<VEC>(a.w + roff, d0, D);
-        if constexpr (OPT == 0) {
-            mrow = load_frag<VEC>(a.m + roff, d0, D);
-            vrow = load_frag<VEC>(a.v + roff, d0, D);
+        own = !err && j < Bn;
+        if (own) {
+            row = a.ks[j];
+            own = ((j > 0) ? a.ks[j - 1] : -2) != row;           // run heads only
         }
     }
-    float gb;
-    const Frag<VEC> gr = run_total<VEC, PIECE>(a.grad_rows, a.grad_bias, a.ks, Bn, j, row, d0, D, gb);
+    const size_t roff = (size_t)row * D;
+    Frag<VEC> w, mrow, vrow, gr;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; gr.v[q] = 0.f; }
+    float gb = 0.f;
+    long long next = -1;
+    if (own) {
+        if (OPT != 2 && !a.frozen_rows) {                // issued before the piece walk
+            w = load_frag<VEC>(a.w + roff, d0, D);
+            if constexpr (OPT == 0) {
+                mrow = load_frag<VEC>(a.m + roff, d0, D);
+                vrow = load_frag<VEC>(a.v + roff, d0, D);
+            }
+        }
+        gr = load_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D);
+        gb = a.grad_bias[j];
+        const int64_t p = (j / PIECE + 1) * PIECE;
+        if (p < Bn && a.ks[p] == row &&
+            add_pieces<VEC, 8>(gr, gb, a.grad_rows, a.grad_bias, a.ks, Bn, j, p, PIECE, row, d0, D))
+            next = p + 8 * (int64_t)PIECE;
+    }
+    if (gl == 0) { s_next[grp] = next; s_row[grp] = row; }
+    if (__syncthreads_or(next >= 0)) {                   // some run of this block is long: share it
+        for (int sl = 0; sl < GPB; ++sl) {
+            const long long ps = s_next[sl];             // block-uniform
+            if (ps < 0) continue;
+            const int32_t rs = s_row[sl];
+            Frag<VEC> part;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) part.v[q] = 0.f;
+            float pb = 0.f;
+            int64_t pp = ps + (int64_t)grp * PIECE;
+            while (add_pieces<VEC, CW>(part, pb, a.grad_rows, a.grad_bias, a.ks, Bn, 0, pp, (int64_t)GPB * PIECE, rs, d0, D))
+                pp += (int64_t)CW * GPB * PIECE;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s_part[threadIdx.x * VEC + q] = part.v[q];
+            if (gl == 0) s_partb[grp] = pb;
+            __syncthreads();
+            if (grp == sl) {
+                for (int g2 = 0; g2 < GPB; ++g2) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) gr.v[q] += s_part[(g2 * G + gl) * VEC + q];
+                    gb += s_partb[g2];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!own) return;
+    const AdamC c = {a.alpha, a.b1, a.b2, a.eps, 1.f - a.b1, 1.f - a.b2};
+    if constexpr (OPT == 2) {                            // sharded step: emit the reduced gradient row
+        store_frag<VEC>(a.w + (a.wstride ? (size_t)row * a.wstride : roff), d0, D, gr);
+        if (gl == 0) a.bias_w[a.wbstride ? (size_t)row * a.wbstride : (size_t)row] = gb;
+        return;
+    }
     if (!a.frozen_rows) {
         if constexpr (OPT == 0) {
 #pragma unroll
