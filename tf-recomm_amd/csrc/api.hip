@@ -1466,8 +1466,9 @@ static uint32_t mask_for(uint32_t rng) {
 
 // Steps whose ids are drawn on the side stream (tfr_train_steps_drawn).  The draws are cut into chunks of whole steps -
 // small ones first, so the first steps start after two batches' worth of draws, then doubling while the generator's
-// lead over the steps allows it - and a chunk is ENQUEUED only when the step loop comes within `ahead` steps of it:
-// the host never spends a long stretch feeding the draw stream while the main stream sits empty.
+// lead over the steps allows it - and a chunk is ENQUEUED when the step loop needs it (need) or one at a time after a step's
+// own launches (feed): the host never spends a stretch feeding the draw stream while the main stream sits empty (a 20-step
+// call: the first step used to start 36 us into the call, behind six draw launches).
 // need(step, stream) makes `stream` wait for the chunk that holds that step's ids.  NULL = ids staged by the host.
 struct IdsReady {
     tfr_model* m = nullptr;
@@ -1476,7 +1477,7 @@ struct IdsReady {
     std::vector<int64_t> first;                            // first[c] = first step of chunk c; first[nchunks] = nsteps
     int enq = 0;                                           // chunks enqueued so far
     int waited[2] = {-1, -1};                              // highest chunk waited for: [0] main stream, [1] stream2
-    int64_t ahead = 4, pre = 0;                            // pre: steps whose ids the previous call drew ahead (chunk 0, event spec_ev)
+    int64_t pre = 0;                                       // pre: steps whose ids the previous call drew ahead (chunk 0, event spec_ev)
     int chunk_of(int64_t step) const {
         int c = 0;
         while (c + 1 < (int)first.size() - 1 && first[c + 1] <= step) ++c;
@@ -1498,11 +1499,11 @@ struct IdsReady {
             if (s + n > nsteps) n = nsteps - s;
         }
         first.push_back(nsteps);
-        ahead = 2 * cap_steps + 2;
     }
-    int enqueue_through(int64_t step) {                    // every chunk that starts at or before `step`
+    // every chunk that starts at or before `step`, and at most `extra` more
+    int enqueue_through(int64_t step, int extra = 0) {
         const int nch = (int)first.size() - 1;
-        while (enq < nch && first[enq] <= step) {
+        while (enq < nch && (first[enq] <= step || extra-- > 0)) {
             const int c = enq++;
             while ((int)m->chunk_ev.size() <= c) {
                 hipEvent_t e;
@@ -1519,9 +1520,13 @@ struct IdsReady {
         }
         return TFR_OK;
     }
+    // after a step's launches: one more chunk for the draw stream (never before them - with ids drawn ahead by the previous
+    // call the first step must not queue behind draw launches it does not need; one per step keeps the host ahead of a
+    // 20-us step and the generator busy from the start, so the run-ahead draw at the end of the call fits inside it)
+    int feed(int64_t step) { return enqueue_through(step, 1); }
     int need(int64_t step, hipStream_t st, int which) {
         if (step >= nsteps) step = nsteps - 1;
-        int rc = enqueue_through(step + ahead);
+        int rc = enqueue_through(step);
         if (rc) return rc;
         const int c = chunk_of(step);
         if (c > waited[which]) {                           // chunks complete in order on the draw stream
@@ -1566,6 +1571,7 @@ static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, i
                                  m->d_ids + (first_step + s) * B, nullptr, true)))
             return rc;
         HIPCHK(hipEventRecord(m->ev_free[z], main_s));
+        if (ready && (rc = ready->feed(first_step + s))) return rc;
         if (s + 1 < nsteps) swap_sortset(m);               // the next step's batch lives in the other set
     }
     HIPCHK(hipStreamSynchronize(m->stream2));              // nothing of ours is left in flight on the side stream
@@ -1597,6 +1603,7 @@ static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nst
             m->pf_valid = false;
             return rc;
         }
+        if (ready && (rc = ready->feed(first_step + s))) return rc;
     }
     }
     if (loss_out) {
