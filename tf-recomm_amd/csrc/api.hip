@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include <new>
+#include <chrono>
 #include <vector>
 #include "tfrecomm.h"
 #include "svd_kernels.h"
@@ -300,6 +301,21 @@ static int check_device_error(tfr_model* m) {
     if (!(m)) return fail(TFR_ERR_ARG, "null model");                 \
     HIPCHK(hipSetDevice((m)->device));
 
+// TFR_CALL_TRACE=1: host-side timestamps (us since the call's entry) of a multi-step call's phases on stderr
+struct CallTrace {
+    bool on; std::chrono::steady_clock::time_point t0; const char* name;
+    explicit CallTrace(const char* n) : name(n) {
+        static int en = -1;
+        if (en < 0) { const char* e = getenv("TFR_CALL_TRACE"); en = (e && e[0] == '1') ? 1 : 0; }
+        on = en == 1;
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    void mark(const char* what) const {
+        if (on) fprintf(stderr, "[%s] %-28s %8.1f us\n", name, what,
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 extern "C" {
 
@@ -543,7 +559,10 @@ int tfr_get_stream(tfr_model* m, void** s) {
 
 int tfr_sync(tfr_model* m) {
     MODEL_ENTER(m);
-    return check_device_error(m);
+    CallTrace tr("sync");
+    const int rc = check_device_error(m);
+    tr.mark("main stream drained");
+    return rc;
 }
 
 int tfr_profile(tfr_model* m, int32_t enable) {
@@ -1532,7 +1551,7 @@ struct IdsReady {
         if (c > waited[which]) {                           // chunks complete in order on the draw stream
             if (hipStreamWaitEvent(st, (c == 0 && pre) ? m->spec_ev : m->chunk_ev[c], 0) != hipSuccess)
                 return fail(TFR_ERR_HIP, "hipStreamWaitEvent failed");
-            waited[which] = c;
+            waited[which] = c;                             // (skipping the wait when hipEventQuery says "done": no gain, A/B)
         }
         return TFR_OK;
     }
@@ -1627,7 +1646,10 @@ int tfr_train_steps_staged(tfr_model* m, int64_t first_step, int64_t B, int32_t 
     if ((first_step + nsteps) * B > m->n_ids)
         return fail(TFR_ERR_ARG, "steps [%lld,%lld) x batch %lld exceed the %lld staged ids", (long long)first_step,
                     (long long)(first_step + nsteps), (long long)B, (long long)m->n_ids);
-    return staged_steps(m, first_step, B, nsteps, loss_out);
+    CallTrace tr("steps_staged");
+    const int rc = staged_steps(m, first_step, B, nsteps, loss_out);
+    tr.mark("all steps enqueued");
+    return rc;
 }
 
 int tfr_train_steps_resident(tfr_model* m, const int64_t* ids, int64_t B, int32_t nsteps, float* loss_out) {
@@ -1745,6 +1767,7 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
     if (nsteps == 0) return TFR_OK;
     int rc;
     if ((rc = check_high(m->N))) return rc;
+    CallTrace tr("steps_drawn");
     const int64_t total = B * (int64_t)nsteps;
     const uint32_t rng = (uint32_t)(m->N - 1);
     int64_t pre = 0;
@@ -1779,7 +1802,9 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
     ready.m = m; ready.B = B; ready.nsteps = nsteps; ready.rng = rng;
     ready.plan(B >= 65536 ? 1 : (65536 / B < 16 ? 65536 / B : 16), pre);     // a chunk holds at most ~64K ids / 16 steps
     if (rng == 0) HIPCHK(hipMemsetAsync(m->d_ids, 0, (size_t)total * 8, m->stream3));   // one-rating store: no draw consumed
+    tr.mark(pre ? "ids drawn ahead taken" : "no ids drawn ahead");
     if ((rc = staged_steps(m, 0, B, nsteps, loss_out, &ready))) return rc;
+    tr.mark("all steps enqueued");
     if ((rc = ready.enqueue_through(nsteps))) return rc;   // (every chunk is out by now; this is a no-op kept for clarity)
     // run ahead: the next call's first batches, into the other buffer (last read by the call before this one)
     if (rng != 0) {
@@ -1804,6 +1829,7 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
         HIPCHK(hipEventRecord(m->spec_ev, m->stream3));
         m->spec_valid = true; m->spec_B = B; m->spec_N = m->N; m->spec_steps = spec;
     }
+    tr.mark("run-ahead draw enqueued");
     return TFR_OK;
 }
 
