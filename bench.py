@@ -322,7 +322,7 @@ def fm_forward_bench(device, steps=50, warmup=5, F=1_000_000, D=64, n=1 << 20, n
     per_launch = n * (nnz * (4 * D + 12) + 4)
     gbs = per_launch / (avg * 1e-3) / 1e9
     G = lane_group(D)
-    kern = "k_fm_forward<%d, %d, false>" % (G, 4 if D % 4 == 0 else 1)
+    kern = "k_fm_forward<%d, %d, false, %s>" % (G, 4 if D % 4 == 0 else 1, "true" if F * D * 4 >= 128 << 20 else "false")   # V streamed past the Infinity Cache
     # training step bytes per non-zero (SGD): forward V row + W + index + value (4D+12); backward: the row's factor sum s_r
     # (4D, gathered per non-zero), own V row read + written (8D), W read + written (8), coefficients / keys / positions of the
     # 3-pass radix sort (~16 B x 3 x 2) -> 16D + ~120

@@ -2486,6 +2486,14 @@ static int fm_stage_csr(tfr_fm* f, const int64_t* indptr, const int32_t* indices
     return TFR_OK;
 }
 
+// k_fm_forward variant (launch_fm): TFR_FM_VARIANT=<bits> overrides for A/B
+static int fm_variant(const tfr_model* m) {
+    static int ov = -2;
+    if (ov == -2) { const char* e = getenv("TFR_FM_VARIANT"); ov = e ? atoi(e) : -1; }
+    if (ov >= 0) return ov;
+    return ((size_t)m->U * m->D * 4 >= ((size_t)128 << 20)) ? 2 : 0;      // V beyond half the Infinity Cache: stream it
+}
+
 static int fm_forward_core(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_indices, const float* d_data,
                            int64_t n_rows, float* d_out) {
     tfr_model* m = f->m;
@@ -2494,6 +2502,7 @@ static int fm_forward_core(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_
     a.V = m->w[TFR_P]; a.W = m->w[TFR_BU]; a.mu = m->w[TFR_MU];
     a.indptr = d_indptr; a.indices = d_indices; a.data = d_data; a.out = d_out; a.err = m->d_err;
     a.n_rows = n_rows; a.F = m->U; a.D = m->D;
+    a.variant = fm_variant(m);
     (void)hipEventRecord(f->ev0, m->stream);
     launch_fm(a, false, m->G, m->VEC, fm_grid(n_rows, m->G, false), m->stream);
     (void)hipEventRecord(f->ev1, m->stream);
@@ -2526,6 +2535,7 @@ static int fm_train_core(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_in
     a.indptr = d_indptr; a.indices = d_indices; a.data = d_data; a.out = d_pred; a.err = m->d_err;
     a.y = d_y; a.s_rows = f->s_rows; a.ent_row = m->d_i; a.ent_a = m->d_g; a.ent_b = m->d_r; a.partials = m->partials;
     a.n_rows = n_rows; a.F = m->U; a.D = m->D; a.loss = o.loss; a.lam = o.reg;
+    a.variant = fm_variant(m);
     const int grid = fm_grid(n_rows, m->G, true);
     (void)hipEventRecord(f->ev0, s);
     {

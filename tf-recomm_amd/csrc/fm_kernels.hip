@@ -17,7 +17,10 @@
 
 namespace tfr {
 
-template <int G, int VEC, bool TRAIN>
+// NTV: V rows by non-temporal loads - a V that outgrows the Infinity Cache streams past it and W, the indices and the values
+// keep it (C5, one gpurun call: 387 -> 376 us; loading a row's indices / values / weights one per lane and handing
+// them round by ds_bpermute instead: no change, and slower together with NTV - not kept).
+template <int G, int VEC, bool TRAIN, bool NTV>
 __global__ __launch_bounds__(256) void k_fm_forward(FmArgs a) {
     constexpr int GPB = 256 / G;
     const int gl = threadIdx.x % G;
@@ -50,10 +53,18 @@ __global__ __launch_bounds__(256) void k_fm_forward(FmArgs a) {
                 const float* vr = a.V + (size_t)f[j] * D;
                 if constexpr (VEC == 4) {
                     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (d0 < D) t = *reinterpret_cast<const float4*>(vr + d0);
+                    if (d0 < D) {
+                        if constexpr (NTV) {
+                            const float* q4 = vr + d0;
+                            t.x = __builtin_nontemporal_load(q4); t.y = __builtin_nontemporal_load(q4 + 1);
+                            t.z = __builtin_nontemporal_load(q4 + 2); t.w = __builtin_nontemporal_load(q4 + 3);
+                        } else {
+                            t = *reinterpret_cast<const float4*>(vr + d0);
+                        }
+                    }
                     v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
                 } else {
-                    v[j][0] = (d0 < D) ? vr[d0] : 0.f;
+                    v[j][0] = (d0 < D) ? (NTV ? __builtin_nontemporal_load(vr + d0) : vr[d0]) : 0.f;
                 }
                 w[j] = a.W[f[j]];
             }
@@ -131,8 +142,9 @@ int fm_grid(int64_t n_rows, int G, bool train) {
 void launch_fm(const FmArgs& a, bool train, int G, int VEC, int grid, hipStream_t s) {
 #define TFR_FM_CASE(g, v)                                                                              \
     if (G == g && VEC == v) {                                                                          \
-        if (train) hipLaunchKernelGGL((k_fm_forward<g, v, true>), dim3(grid), dim3(256), 0, s, a);     \
-        else hipLaunchKernelGGL((k_fm_forward<g, v, false>), dim3(grid), dim3(256), 0, s, a);          \
+        if (train) hipLaunchKernelGGL((k_fm_forward<g, v, true, false>), dim3(grid), dim3(256), 0, s, a);     \
+        else if (a.variant & 2) hipLaunchKernelGGL((k_fm_forward<g, v, false, true>), dim3(grid), dim3(256), 0, s, a);   \
+        else hipLaunchKernelGGL((k_fm_forward<g, v, false, false>), dim3(grid), dim3(256), 0, s, a);   \
         return;                                                                                        \
     }
     TFR_FM_CASE(4, 4) TFR_FM_CASE(8, 4) TFR_FM_CASE(16, 4) TFR_FM_CASE(32, 4) TFR_FM_CASE(64, 4)

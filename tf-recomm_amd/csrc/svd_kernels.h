@@ -143,6 +143,7 @@ struct FmArgs {
     int64_t n_rows, F;
     int32_t D, loss;
     float lam;
+    int32_t variant;                               // bit 1: non-temporal V rows (inference; launch_fm)
 };
 int fm_grid(int64_t n_rows, int G, bool train);
 void launch_fm(const FmArgs& a, bool train, int G, int VEC, int grid, hipStream_t s);
