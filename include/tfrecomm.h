@@ -129,6 +129,15 @@ int tfr_auc_dev(tfr_model* m, const float* d_score, const float* d_label, int64_
 int tfr_train_step(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
                    int64_t batch, float* logits_out, float* loss_out, float* reg_out);
 
+/* ---- the same minibatch nsteps times: the inner loop of the per-user fine-tuning drivers - adaptive_test.py:104-116
+ *      (EPOCH_MAX = 300 x sess.run(train_op) on the asked items of one user) and non_adaptive_test.py:82-87 (100 x on the
+ *      user's history), usually with tfr_set_frozen = var_list=[user_bias, user_features] (adaptive_test.py:28).  The batch
+ *      is uploaded once and the steps run with no host round trip in between.  logits_out[batch]: pre-update logits of the
+ *      LAST step (what the last sess.run would fetch); loss_out[nsteps]: data term per step.  Either may be NULL.  Same
+ *      result, bit for bit, as nsteps calls of tfr_train_step. */
+int tfr_train_steps_repeat(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,
+                           int64_t batch, int32_t nsteps, float* logits_out, float* loss_out);
+
 /* ---- device-resident (user,item,rate) store: the feed of dataio.ShuffleIterator
  *      (dataio.py:98-103,114-117) kept in HBM; the host still draws the ids. */
 int tfr_upload_triples(tfr_model* m, const int32_t* user, const int32_t* item, const float* rate,

@@ -8,8 +8,9 @@ kernels behind the C-ABI of include/tfrecomm.h.  Import as ``import tfrecomm_amd
 from . import _lib
 from ._lib import TfrError, OutOfRangeError
 from .engine import SvdModel
-from . import dataio, graph, ops, config
+from . import dataio, graph, ops, config, cats, adaptive_test
 from .fm import FmModel
 from .als import MangakiALS3
 
-__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config", "FmModel", "MangakiALS3"]
+__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config", "cats", "adaptive_test",
+           "FmModel", "MangakiALS3"]

@@ -74,6 +74,7 @@ SIGNATURES = {
     "tfr_train_steps_resident": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, _f32p]),
     "tfr_stage_ids": (C.c_int, [_p, _i64p, C.c_int64]),
     "tfr_train_steps_staged": (C.c_int, [_p, C.c_int64, C.c_int64, C.c_int32, _f32p]),
+    "tfr_train_steps_repeat": (C.c_int, [_p, _i32p, _i32p, _f32p, C.c_int64, C.c_int32, _f32p, _f32p]),
     "tfr_forward_resident": (C.c_int, [_p, C.c_int64, C.c_int64, _f32p]),
     "tfr_rng_seed": (C.c_int, [_p, C.c_uint32]),
     "tfr_rng_set_state": (C.c_int, [_p, C.POINTER(C.c_uint32), C.c_int32]),

@@ -1321,6 +1321,46 @@ int tfr_train_step(tfr_model* m, const int32_t* u, const int32_t* i, const float
     return TFR_OK;
 }
 
+int tfr_train_steps_repeat(tfr_model* m, const int32_t* u, const int32_t* i, const float* r, int64_t B, int32_t nsteps,
+                           float* logits_out, float* loss_out) {
+    MODEL_ENTER(m);
+    int rc = check_batch(u, i, B);
+    if (rc) return rc;
+    if (B < 1 || !r) return fail(TFR_ERR_ARG, "train_steps_repeat: need a batch of at least one rating");
+    if (nsteps < 0) return fail(TFR_ERR_ARG, "bad nsteps");
+    if (nsteps == 0) return TFR_OK;
+    if ((rc = ensure_capacity(m, B))) return rc;
+    if (loss_out && (rc = ensure_step_out(m, nsteps))) return rc;
+    const int64_t step0 = m->step;
+    const float b1p0 = m->b1p, b2p0 = m->b2p;
+    m->last_r = nullptr;
+    HIPCHK(hipMemcpyAsync(m->d_u, u, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_i, i, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_r, r, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+    for (int32_t s = 0; s < nsteps; ++s) {
+        const bool last = s + 1 == nsteps;
+        if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, (last && logits_out) ? m->d_logits : nullptr,
+                                 loss_out ? m->step_out + (size_t)s * 4 : nullptr))) {
+            (void)hipStreamSynchronize(m->stream);
+            rollback_step(m, step0, b1p0, b2p0);
+            return rc;
+        }
+    }
+    std::vector<float> tmp;
+    if (loss_out) {
+        tmp.resize((size_t)nsteps * 4);
+        HIPCHK(hipMemcpyAsync(tmp.data(), m->step_out, tmp.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    }
+    if (logits_out) HIPCHK(hipMemcpyAsync(logits_out, m->d_logits, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    if ((rc = check_device_error(m))) {                    // a bad id voids every step of the call
+        rollback_step(m, step0, b1p0, b2p0);
+        return rc;
+    }
+    for (int32_t s = 0; loss_out && s < nsteps; ++s) loss_out[s] = tmp[(size_t)s * 4];
+    if (logits_out) { m->last_r = m->d_r; m->last_B = B; }
+    return TFR_OK;
+}
+
 /* roc_auc_score(rates, sigmoid(logits)) of the batch the last tfr_train_step ran on (its pre-update logits, the ones
  * the caller was handed): svd_train_val.py:97, without sklearn on the host.  Needs that call to have asked for logits. */
 int tfr_last_batch_auc(tfr_model* m, double* auc_out) {

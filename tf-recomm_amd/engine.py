@@ -171,6 +171,20 @@ class SvdModel:
                                          C.byref(loss), C.byref(reg)))
         return logits, loss.value, reg.value
 
+    def train_steps_repeat(self, users, items, rates, nsteps, want_logits=True, want_loss=True):
+        """``for _ in range(nsteps): sess.run(train_op, feed_dict)`` on ONE batch (the per-user fine-tuning loops of
+        adaptive_test.py:104-116 / non_adaptive_test.py:82-87) without a host round trip between the steps.
+        Returns (pre-update logits of the last step, data loss per step)."""
+        u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
+        if not (u.shape == i.shape == r.shape) or u.ndim != 1:
+            raise ValueError("batches must be 1-D and of equal length")
+        logits = np.empty(u.size, np.float32) if want_logits else None
+        loss = np.empty(int(nsteps), np.float32) if want_loss else None
+        L.check(self._lib.tfr_train_steps_repeat(self._h, L.ptr_i32(u), L.ptr_i32(i), L.ptr_f32(r), u.size, int(nsteps),
+                                                 L.ptr_f32(logits) if want_logits else None,
+                                                 L.ptr_f32(loss) if want_loss else None))
+        return logits, loss
+
     # -- resident store -----------------------------------------------------------
     def upload_triples(self, users, items, rates):
         u, i, r = L.as_i32(users, "user ids"), L.as_i32(items, "item ids"), L.as_f32(rates)
