@@ -52,6 +52,38 @@ def test_fm_random_csr_matches_oracle_and_scipy_path(F, D, n, nnz):
     assert_close(yb, ref, rtol=2e-5, what="fm binary")
 
 
+def test_fm_config5_full_size_properties():
+    """BASELINE config 5 at its full table size (1M features x 64: V = 256 MB, read by the non-temporal variant of the
+    kernel) on 2^18 rows x 8 non-zeros: a row's prediction depends on its own non-zeros only, so (i) 4096 rows drawn from
+    the batch equal the oracle on those rows alone, (ii) the batch in another row order gives the same numbers, bit for
+    bit, in that order, (iii) the empty row predicts mu."""
+    F, D, n, nnz = 1_000_000, 64, 1 << 18, 8
+    rs = np.random.RandomState(5)
+    V = rs.normal(0, 0.1, (F, D)).astype(np.float32)
+    W = rs.normal(0, 0.1, F).astype(np.float32)
+    mu = np.float32(-0.21)
+    indptr = np.arange(0, (n + 1) * nnz, nnz, dtype=np.int64)
+    indptr[1:] -= nnz                                     # row 0 is empty
+    indptr[0] = 0
+    indices = rs.randint(0, F, (n - 1) * nnz).astype(np.int32)
+    data = rs.randint(1, 4, (n - 1) * nnz).astype(np.float32)
+    with T.FmModel(F, D) as m:
+        m.set(mu, W, V)
+        y = m.forward_csr(indptr, indices, data)
+        pick = np.concatenate([[0], rs.choice(np.arange(1, n), 4095, replace=False)])
+        sub_ptr = np.zeros(pick.size + 1, np.int64)
+        sub_ptr[1:] = np.cumsum(indptr[pick + 1] - indptr[pick])
+        sub_idx = np.concatenate([indices[indptr[r]:indptr[r + 1]] for r in pick])
+        sub_val = np.concatenate([data[indptr[r]:indptr[r + 1]] for r in pick])
+        want = so.fm_forward(np.float64(mu), W.astype(np.float64), V.astype(np.float64), sub_ptr, sub_idx, sub_val.astype(np.float64))
+        assert_close(y[pick], want, rtol=2e-5, what="fm rows against the oracle")
+        assert abs(y[0] - mu) < 1e-6
+        perm = rs.permutation(n)
+        X = sp.csr_matrix((data, indices, indptr), shape=(n, F))[perm]
+        y2 = m.forward_csr(X.indptr.astype(np.int64), X.indices.astype(np.int32), X.data.astype(np.float32))
+        assert np.array_equal(y2, y[perm])
+
+
 def test_fm_errors():
     with T.FmModel(100, 8) as m:
         m.init(seed=1)
