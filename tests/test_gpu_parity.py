@@ -190,9 +190,12 @@ def test_sort_segments_bit_exact(golden):
         assert np.array_equal(ids[first], g[key + "/unique_first_occurrence"])
 
 
-def test_sort_large_random_matches_numpy():
+@pytest.mark.parametrize("B", [262144, 3_000_000, 40_000_000])
+def test_sort_large_random_matches_numpy(B):
+    """262144: the C3 batch; 3 M keys: the scatter takes the scan blocks' totals from its LDS prefix (FM non-zeros are sorted at
+    this size); 40 M keys: more scan blocks than that prefix holds."""
     rs = np.random.RandomState(5)
-    n, B = 10_000_000, 262144
+    n = 10_000_000
     ids = rs.randint(0, n, B).astype(np.int32)
     with T.SvdModel(n, 16, 4, optimizer="sgd") as m:
         ks, ps = m.sort_segments(0, ids)

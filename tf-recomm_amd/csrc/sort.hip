@@ -246,12 +246,44 @@ __global__ __launch_bounds__(1024) void k_rsort_scan(RSortArgs a) {
 __global__ __launch_bounds__(CSORT_TILE) void k_rsort_scatter(RSortArgs a) {
     const int col = blockIdx.y, tile = blockIdx.x;
     const int64_t k = (int64_t)tile * CSORT_TILE + threadIdx.x;
+    // millions of keys (FM non-zeros: 8.4 M keys = 512 scan blocks): the totals of the preceding scan blocks are
+    // prefix-summed once per block in LDS instead of being added up key by key (FM training step 3.1 -> 2.56 ms)
+    constexpr int PREF = 2 * CSORT_TILE;
+    __shared__ int32_t pref[PREF];
+    __shared__ int32_t pw[CSORT_TILE / 64];
+    const int64_t nb = ((int64_t)256 * a.ntiles + a.chunk - 1) / a.chunk;
+    const bool use_pref = nb > 32;                           // block-uniform
+    if (use_pref) {
+        const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+        const int32_t x0 = (2 * t < nb && 2 * t < PREF) ? a.blocktot[col][2 * t] : 0;
+        const int32_t x1 = (2 * t + 1 < nb && 2 * t + 1 < PREF) ? a.blocktot[col][2 * t + 1] : 0;
+        int32_t incl = x0 + x1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) pw[wave] = incl;
+        __syncthreads();
+        int32_t run = incl - (x0 + x1);
+        for (int w = 0; w < wave; ++w) run += pw[w];
+        pref[2 * t] = run;                                   // exclusive: totals of the blocks before 2t
+        pref[2 * t + 1] = run + x0;
+        __syncthreads();
+    }
     if (k >= a.B) return;
     const int32_t key = a.keys_in[col][k];
     const int32_t digit = (key >> a.shift) & 255;
     const int64_t idx = (int64_t)digit * a.ntiles + tile;
     int32_t base = 0;
-    for (int q = 0; q < (int)(idx / a.chunk); ++q) base += a.blocktot[col][q];
+    const int qn = (int)(idx / a.chunk);
+    if (use_pref) {
+        const int covered = qn < PREF ? qn : PREF - 1;       // pref[PREF-1] = totals of blocks 0..PREF-2
+        base = pref[covered];
+        for (int q = covered; q < qn; ++q) base += a.blocktot[col][q];
+    } else {
+        for (int q = 0; q < qn; ++q) base += a.blocktot[col][q];
+    }
     const int32_t dst = base + a.offs[col][idx] + a.lrank[col][k];
     a.keys_out[col][dst] = key;
     a.vals_out[col][dst] = a.vals_in[col] ? a.vals_in[col][k] : (int32_t)k;
