@@ -402,6 +402,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5", "als"])
     ap.add_argument("--adam-mode", default=None, choices=["tf1", "lazy"])
     ap.add_argument("--store-ratings", type=int, default=None, help="override the size of the rating store")
+    ap.add_argument("--dim", type=int, default=None, help="override the workload's dim (not the BASELINE configuration: for kernel studies)")
     ap.add_argument("--zipf", type=float, default=0.0, help="c3/c4 training store: item ids ~ Zipf(a) instead of uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
@@ -469,6 +470,9 @@ def main():
         wl["adam_mode"] = args.adam_mode
     if args.store_ratings:
         wl["N"] = args.store_ratings
+    if args.dim:
+        wl["D"] = args.dim
+        wl["name"] = wl["name"] + " [dim overridden to %d]" % args.dim
     U, I, D, B = wl["U"], wl["I"], wl["D"], wl["B"]
     K, W = args.steps, args.warmup
 
