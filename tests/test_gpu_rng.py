@@ -35,7 +35,11 @@ def test_draw_matches_numpy_and_leaves_numpy_state(model):
     # ranges around powers of two (no rejection / ~50 % rejection), tiny, ML-1M's 900188, 90M; counts that
     # end inside, exactly at and just past a 624-word block
     cases = [(900188, 10000), (7, 5), (1 << 20, 3000), ((1 << 20) + 1, 3000), (90_000_000, 5000), (2, 1), (2, 623), (2, 1),
-             (2, 624), (2, 625), (1, 17), (3, 0), ((1 << 32) - 1, 2000), (1 << 32, 1500), (1000209, 262144)]
+             (2, 624), (2, 625), (1, 17), (3, 0), ((1 << 32) - 1, 2000), (1 << 32, 1500), (1000209, 262144),
+             # the wide form (k_mt_blocks / k_mt_count / k_mt_emit, from 32768 ids): at its threshold, without rejection, at ~50 %
+             # rejection, the C3 draw, tiny ranges, and more ids than one wide pass holds (2^22)
+             (900188, 32767), (900188, 32768), (1 << 20, 65536), ((1 << 20) + 1, 100000), (90_000_000, 262144), (2, 40000),
+             (3, 50001), (70_000_000, 5_000_000), (1 << 32, 33000), ((1 << 31) + 1, 70000)]
     for high, count in cases:
         want = np.random.randint(0, high, (count,))
         got = m.draw_ids(high, count)
@@ -52,6 +56,29 @@ def test_draw_matches_numpy_and_leaves_numpy_state(model):
     np.random.seed(1)
     m.rng_to_numpy()                                             # back to where the device is
     assert np.array_equal(np.random.randint(0, 999, 100), m.draw_ids(999, 100))
+
+
+def test_wide_draw_that_comes_up_short_is_finished_by_the_sequential_kernel():
+    """TFR_RNG_WIDE_TRIM makes the wide form generate too few blocks: the k_mt_draw launch behind it draws the rest from
+    the state the last block left - same ids, same final state (a fresh process: the switch is read once)."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, torch\n"
+        "torch.cuda.init(); torch.zeros(1, device='cuda')\n"
+        "import tfrecomm_amd as T\n"
+        "m = T.SvdModel(50, 40, 8, device=0)\n"
+        "np.random.seed(7); m.rng_seed(7)\n"
+        "for high, count in ((900188, 50000), ((1 << 20) + 1, 262144), (90_000_000, 40000)):\n"
+        "    want = np.random.randint(0, high, (count,)); got = m.draw_ids(high, count)\n"
+        "    assert np.array_equal(got, want), (high, count)\n"
+        "    key, pos = m.rng_get_state(); st = np.random.get_state()\n"
+        "    assert pos == st[2] and np.array_equal(key, st[1]), (high, count)\n"
+        "print('short draws ok')\n")
+    for trim in ("60", "97"):
+        env = dict(os.environ, TFR_RNG_WIDE_TRIM=trim)
+        out = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "short draws ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_draw_matches_the_reference_iterators_own_streams(model, golden):

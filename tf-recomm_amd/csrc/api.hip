@@ -87,6 +87,7 @@ struct tfr_model {
     int64_t alt_cap = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_first = nullptr;
+    MtScratch rng_ws = {nullptr, nullptr, nullptr, 0};     // wide form of the id draw (rng.hip), allocated with the generator state
     hipEvent_t ev_mid = nullptr; bool ev_mid_on = false;   // recorded between the item-side and the user-side kernel of a big-table step
     // resident store
     int4* store = nullptr;            // {user, item, rate bits, -} per rating
@@ -358,6 +359,7 @@ int tfr_destroy(tfr_model* m) {
     for (auto e : m->chunk_ev) (void)hipEventDestroy(e);
     if (m->ev_ids_free) (void)hipEventDestroy(m->ev_ids_free);
     dfree(m->d_rng); dfree(m->d_ring); dfree(m->d_ids_alt); dfree(m->d_rng_snap);
+    dfree(m->rng_ws.raw); dfree(m->rng_ws.counts); dfree(m->rng_ws.hdr);
     dfree(m->rt_mine); dfree(m->rt_u); dfree(m->rt_it); dfree(m->rt_r); dfree(m->rt_slot); dfree(m->rt_counts);
     if (m->spec_ev) (void)hipEventDestroy(m->spec_ev);
     if (m->h_ring) (void)hipHostFree(m->h_ring);
@@ -1576,7 +1578,7 @@ struct IdsReady {
             const int64_t s0 = first[c], s1 = first[c + 1];
             hipEvent_t pa = nullptr, pb = nullptr;
             if (m->prof && hipEventCreate(&pa) == hipSuccess && hipEventCreate(&pb) == hipSuccess) (void)hipEventRecord(pa, m->stream3);
-            if (rng != 0) launch_mt_draw(m->d_rng, m->d_ids + s0 * B, (s1 - s0) * B, rng, mask_for(rng), m->stream3);
+            if (rng != 0) launch_mt_draw(m->d_rng, m->d_ids + s0 * B, (s1 - s0) * B, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
             if (pa && pb) { (void)hipEventRecord(pb, m->stream3); m->events.push_back({pa, pb, TFR_K_DRAW}); }
             if (hipGetLastError() != hipSuccess || hipEventRecord(m->chunk_ev[c], m->stream3) != hipSuccess)
                 return fail(TFR_ERR_HIP, "draw launch failed");
@@ -1740,6 +1742,14 @@ static int ensure_rng(tfr_model* m) {
         int rc;
         if ((rc = dmalloc(&m->d_rng, 625))) return rc;
         if ((rc = dmalloc(&m->d_rng_snap, 625))) return rc;
+        // scratch of the wide draw; TFR_RNG_WIDE=0 keeps every draw on the one-workgroup kernel (A/B)
+        const char* e = getenv("TFR_RNG_WIDE");
+        if (!(e && e[0] == '0')) {
+            if ((rc = dmalloc(&m->rng_ws.raw, (size_t)MT_WIDE_BLOCKS * 624))) return rc;
+            if ((rc = dmalloc(&m->rng_ws.counts, (size_t)MT_WIDE_BLOCKS))) return rc;
+            if ((rc = dmalloc(&m->rng_ws.hdr, 4))) return rc;
+            m->rng_ws.cap_blocks = MT_WIDE_BLOCKS;
+        }
     }
     if (!m->stream3) {
         HIPCHK(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
@@ -1814,7 +1824,7 @@ int tfr_draw_ids(tfr_model* m, int64_t high, int64_t count, int64_t* ids_out) {
     const uint32_t rng = (uint32_t)(high - 1);
     unsigned long long* dbg = nullptr;
     if (getenv("TFR_RNG_DEBUG")) (void)hipMalloc((void**)&dbg, 16);           // diagnostic: in-kernel clock of the generator
-    launch_mt_draw(m->d_rng, d, count, rng, mask_for(rng), m->stream3, dbg);
+    launch_mt_draw(m->d_rng, d, count, rng, mask_for(rng), m->stream3, dbg, &m->rng_ws);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ids_out, d, (size_t)count * 8, hipMemcpyDeviceToHost, m->stream3);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream3);
@@ -1896,7 +1906,7 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
         }
         HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));  // the alternate buffer's last readers (before this call) are done
         HIPCHK(hipMemcpyAsync(m->d_rng_snap, m->d_rng, 625 * 4, hipMemcpyDeviceToDevice, m->stream3));
-        launch_mt_draw(m->d_rng, m->d_ids_alt, spec * B, rng, mask_for(rng), m->stream3);
+        launch_mt_draw(m->d_rng, m->d_ids_alt, spec * B, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(m->spec_ev, m->stream3));
         m->spec_valid = true; m->spec_B = B; m->spec_N = m->N; m->spec_steps = spec;

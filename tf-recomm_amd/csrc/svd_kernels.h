@@ -250,8 +250,14 @@ void launch_gather_packed(const GatherPackedArgs& a, int G, int VEC, hipStream_t
 void launch_pad_keys(const int32_t* ids_in, int32_t* keys_out, int64_t n, int32_t pad_key, int32_t* count, hipStream_t s);
 
 // rng.hip: NumPy's legacy randint(0, rng + 1, (need,)) from the MT19937 state {key[624], pos} at d_state
+// ws (optional): scratch of the wide form - raw[cap_blocks * 624] words, counts[cap_blocks], hdr[4]; draws of MT_WIDE_MIN ids
+// and more then run as k_mt_blocks + k_mt_count + k_mt_emit (+ a k_mt_draw launch that normally has nothing left to do)
+struct MtScratch { uint32_t* raw; int32_t* counts; int32_t* hdr; int64_t cap_blocks; };
+constexpr int64_t MT_WIDE_MIN = 32768;                   // ids per draw from which the wide form pays for its three extra launches
+constexpr int64_t MT_WIDE_MAX = (int64_t)1 << 22;        // ids per wide pass (scratch: 34 MB at the worst acceptance rate)
+constexpr int64_t MT_WIDE_BLOCKS = 13700;                // 2^22 ids at acceptance 1/2 + 6 sigma, in 624-word blocks
 void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rng, uint32_t mask, hipStream_t s,
-                    unsigned long long* d_dbg = nullptr);     // d_dbg: optional {shader cycles, 100 MHz ticks} of the launch
+                    unsigned long long* d_dbg = nullptr, const MtScratch* ws = nullptr);     // d_dbg: optional {shader cycles, 100 MHz ticks} of the launch
 
 // sort.hip
 constexpr int CSORT_TILE = 1024;
