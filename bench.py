@@ -563,7 +563,7 @@ def main():
         if n:
             ab = algo_bytes(slot, B, D, U, I, wl["adam_mode"], small)
             per_step_us = tot_ms / kp * 1e3
-            kern[slot] = dict(kernel=plan.get(slot, {"draw": "k_mt_draw (side stream)"}.get(slot, slot)), launches_per_step=n / kp,
+            kern[slot] = dict(kernel=plan.get(slot, {"draw": "k_mt_draw, or k_mt_blocks + k_mt_count + k_mt_emit from 32768 ids per draw (side stream)"}.get(slot, slot)), launches_per_step=n / kp,
                               us_per_step=per_step_us, algorithmic_bytes_per_step=ab,
                               achieved_GBps=(ab / (per_step_us * 1e-6) / 1e9 if ab and per_step_us > 0 else None))
     on_path = {k: v for k, v in kern.items() if k != "draw"}
