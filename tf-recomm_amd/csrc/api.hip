@@ -835,11 +835,45 @@ static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, 
     ts.lam = o.reg;
     *par_out = par;
     *nblk_out = ts.ntiles * m->G;            // one {loss, reg, sum g} slot per piece
+    static int dbg_on = -1;                  // TFR_TILE_DEBUG=1: per-block start / end stamps of every launch on stderr (synchronises)
+    if (dbg_on < 0) { const char* e = getenv("TFR_TILE_DEBUG"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+    static unsigned long long* d_dbg = nullptr;
+    if (dbg_on && !d_dbg) (void)hipMalloc((void**)&d_dbg, 2048 * 64);
+    if (dbg_on && d_dbg && 2 * (ts.next_ntiles + ts.ntiles * m->G) <= 2048) { (void)hipMemsetAsync(d_dbg, 0, 2048 * 64, m->stream); ts.dbg = d_dbg; }
     {
         Prof p(m, TFR_K_REDUCE_ITEM);
         launch_tile_step(ts, m->G, m->VEC, m->stream);
     }
     HIPCHK(hipGetLastError());
+    if (ts.dbg) {
+        std::vector<unsigned long long> h(2048 * 8);
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t k = 0; k < h.size(); k += 8) if (h[k]) { if (h[k] < t0) t0 = h[k]; if (h[k + 1] > t1) t1 = h[k + 1]; }
+        const int nsort = ts.next_ids ? 2 * ts.next_ntiles : 0;
+        const size_t gridx = (size_t)nsort + (size_t)ts.ntiles * (m->G / tile_step_epg(ts.ntiles, m->G, m->VEC));
+        double ahead_end = 0, ahead_dur = 0, comp_end = 0, comp_dur = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int nblocks = 0, ncomp = 0;
+        for (size_t k = 0; k < h.size() / 8; ++k) {
+            const unsigned long long* b = &h[8 * k];
+            if (!b[0]) continue;
+            ++nblocks;
+            const double st = (b[0] - t0) / 100.0, en = (b[1] - t0) / 100.0;
+            const bool ah = k < gridx && (int)k < nsort;                // blockIdx.y == 0 and blockIdx.x < nsort
+            if (ah) { if (en > ahead_end) ahead_end = en; if (en - st > ahead_dur) ahead_dur = en - st; }
+            else {
+                if (en > comp_end) comp_end = en;
+                if (en - st > comp_dur) comp_dur = en - st;
+                if (b[2] && b[6]) { ++ncomp; for (int q = 2; q <= 6; ++q) ph[q] += (b[q] - b[0]) / 100.0; ph[7] += en - st; }
+            }
+        }
+        fprintf(stderr, "[k_tile_step] %d blocks (%d look-ahead): span %.2f us; look-ahead blocks end by %.2f (longest %.2f), step blocks end by "
+                        "%.2f (longest %.2f); mean step block, us since its start: records %.2f, rows+contributions %.2f, wave sums staged %.2f, "
+                        "partials %.2f, wave rounds %.2f, end %.2f\n", nblocks, nsort, (t1 - t0) / 100.0, ahead_end, ahead_dur, comp_end, comp_dur,
+                ph[2] / (ncomp ? ncomp : 1), ph[3] / (ncomp ? ncomp : 1), ph[4] / (ncomp ? ncomp : 1), ph[5] / (ncomp ? ncomp : 1),
+                ph[6] / (ncomp ? ncomp : 1), ph[7] / (ncomp ? ncomp : 1));
+    }
     return TFR_OK;
 }
 

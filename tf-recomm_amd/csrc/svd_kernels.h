@@ -175,6 +175,7 @@ struct TileStepArgs {
     // look-ahead: sort the NEXT batch (rows next_ids[0..next_B) of the store) in spare blocks of this launch
     const int64_t* next_ids; int64_t next_B; int32_t next_ntiles;
     int32_t* next_tab[2]; int4* next_srt[2];
+    unsigned long long* dbg;                                 // TFR_TILE_DEBUG: {start, end} of every block, 100 MHz ticks
 };
 void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s);
 // LDS of k_tile_step<G, VEC, EPG>: the static arrays (the kernel static_asserts this sum against its own

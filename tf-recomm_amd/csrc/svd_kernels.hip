@@ -542,6 +542,11 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     static_assert(sizeof(rec_u) + sizeof(rec_i) + sizeof(srt_key) + sizeof(srt_pos) + sizeof(rec_r) + sizeof(lds_gb) + sizeof(lds_key) +
                   sizeof(lds_stage) + sizeof(wtot) == tile_step_static_lds(G, EPG), "tile_step_static_lds() is out of date");
     static_assert(tile_step_static_lds(G, EPG) + 64 * 1024 <= LDS_PER_CU, "static LDS leaves no room for 16384 sort bins");
+    struct Stamp {                                       // diagnostic (TFR_TILE_DEBUG): when did this block start, pass its phases, end?
+        unsigned long long* p; unsigned long long t0;
+        __device__ void mark(int k) const { if (p && threadIdx.x == 0) p[k] = __builtin_amdgcn_s_memrealtime(); }
+        __device__ ~Stamp() { if (p && threadIdx.x == 0) { p[0] = t0; p[1] = __builtin_amdgcn_s_memrealtime(); } }
+    } stamp = {a.dbg ? a.dbg + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) : nullptr, a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull};
     const int tid = threadIdx.x;
     const bool ahead = (int)blockIdx.x < nsort;          // look-ahead block: sort (side, tile) of the next batch
     if (ahead && blockIdx.y) return;
@@ -583,19 +588,34 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     int32_t row[EPG], uu[EPG], ii[EPG];
     float rr[EPG];
     bool ev[EPG], pstart[EPG];
+    int4 rec_[EPG];
+    int32_t prev_[EPG];
 #pragma unroll
     for (int h = 0; h < EPG; ++h) {
         jl[h] = slice * EPS + h * EPB + grp;
         ev[h] = jl[h] < nvalid;
+        rec_[h] = make_int4(0, 0, 0, 0); prev_[h] = -2;
+    }
+    if (presorted) {                                     // the published records of all EPG entries in one round trip (see the
+#pragma unroll                                           // row gathers below for why they are not written `if (ev) rec = *sr`)
+        for (int h = 0; h < EPG; ++h) {
+            const int js = ev[h] ? jl[h] : 0;            // slot 0 of the tile always exists
+            const int4* sr = a.srt[side] + tile0 + js;
+            rec_[h] = *sr;
+            prev_[h] = reinterpret_cast<const int32_t*>(sr - (js > 0 ? 1 : 0))[side];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int h = 0; h < EPG; ++h) {
         row[h] = -1; uu[h] = 0; ii[h] = 0; rr[h] = 0.f; bpos[h] = 0;
         int32_t prev = -2;
         if (ev[h]) {
             if (presorted) {
-                const int4* sr = a.srt[side] + tile0 + jl[h];
-                const int4 rec = *sr;
+                const int4 rec = rec_[h];
                 uu[h] = rec.x; ii[h] = rec.y; rr[h] = __int_as_float(rec.z); bpos[h] = rec.w;
                 row[h] = side == 0 ? rec.x : rec.y;
-                if (jl[h] > 0) prev = reinterpret_cast<const int32_t*>(sr - 1)[side];
+                if (jl[h] > 0) prev = prev_[h];
             } else {
                 row[h] = srt_key[jl[h]];
                 if (jl[h] > 0) prev = srt_key[jl[h] - 1];
@@ -605,18 +625,40 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
         }
         pstart[h] = ev[h] && (prev != row[h] || grp == 0);       // run head, or first entry of the piece
     }
+    if (a.dbg) { if (row[0] == -12345) return; stamp.mark(2); }       // records have arrived
+    // All row and bias gathers of the block's entries in flight together: unconditional loads from addresses that are
+    // always valid (entry slots past the tile's end read row 0, lanes past the row's end its first words), a scheduling
+    // barrier, and only then the zeroing of what did not count.  Written as `if (ev) p = load_frag(...)` the compiler
+    // merged the loaded registers with the zeros of the other path by copies behind an s_waitcnt vmcnt(0), so the P row
+    // of an entry had to arrive before its Q row was requested, and entry 0 before entry 1: three memory round trips
+    // instead of one (ISA of k_tile_step<16,4,2>).
     Frag<VEC> p[EPG], q[EPG];
     float bu_[EPG], bi_[EPG];
+    {
+        const bool in = d0 < D;
+        const int dd = in ? d0 : 0;
 #pragma unroll
-    for (int h = 0; h < EPG; ++h) {                      // all row gathers in flight together
+        for (int h = 0; h < EPG; ++h) {
+            const float* pr = a.P + (size_t)(ev[h] ? uu[h] : 0) * D + dd;
+            const float* qr = a.Q + (size_t)(ev[h] ? ii[h] : 0) * D + dd;
+            if constexpr (VEC == 4) {
+                const floatx4 tp = *reinterpret_cast<const floatx4*>(pr), tq = *reinterpret_cast<const floatx4*>(qr);
+                p[h].v[0] = tp.x; p[h].v[1] = tp.y; p[h].v[2] = tp.z; p[h].v[3] = tp.w;
+                q[h].v[0] = tq.x; q[h].v[1] = tq.y; q[h].v[2] = tq.z; q[h].v[3] = tq.w;
+            } else {
+                p[h].v[0] = *pr; q[h].v[0] = *qr;
+            }
+            bu_[h] = a.bu[ev[h] ? uu[h] : 0];
+            bi_[h] = a.bi[ev[h] ? ii[h] : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { p[h].v[e] = 0.f; q[h].v[e] = 0.f; }
-        bu_[h] = 0.f; bi_[h] = 0.f;
-        if (ev[h]) {
-            p[h] = load_frag<VEC>(a.P + (size_t)uu[h] * D, d0, D);
-            q[h] = load_frag<VEC>(a.Q + (size_t)ii[h] * D, d0, D);
-            bu_[h] = a.bu[uu[h]];
-            bi_[h] = a.bi[ii[h]];
+        for (int h = 0; h < EPG; ++h) {
+            const bool keep = ev[h] && in;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { p[h].v[e] = keep ? p[h].v[e] : 0.f; q[h].v[e] = keep ? q[h].v[e] : 0.f; }
+            bu_[h] = ev[h] ? bu_[h] : 0.f;
+            bi_[h] = ev[h] ? bi_[h] : 0.f;
         }
     }
     Frag<VEC> acc[EPG];
@@ -668,6 +710,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
             gb[h] = a.reg_bias ? (gk + a.lam * ob) : gk;
         }
     }
+    if (a.dbg) { if (gb[0] == -12345.f) return; stamp.mark(3); }      // rows have arrived, contributions formed
     // ---- K3 inside each piece, in two levels, every sum in a fixed tree order (bit-identical run to
     //      run however long the runs are):
     //      1. a wave holds GPW consecutive entries of the piece: suffix sums within runs by doubling,
@@ -711,8 +754,10 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
             if (gl == 0) { wgb[0][w0] = tgb[h]; lds_key[w0] = row[h]; }
         }
     }
+    stamp.mark(4);                                       // wave-level sums staged
     if (side == 1) block_sum_pieces<G, EPG>(facc, lds_stage, a.partials + (size_t)bx * EPG * 4);   // has the barrier
     else __syncthreads();
+    stamp.mark(5);
     int cur = 0;
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) {
@@ -736,6 +781,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
         __syncthreads();
         cur ^= 1;
     }
+    stamp.mark(6);                                       // the four doubling rounds over the waves
 #pragma unroll
     for (int h = 0; h < EPG; ++h) {
         const int w1 = h * 16 + wv + 1;
