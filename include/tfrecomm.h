@@ -214,6 +214,11 @@ int32_t tfr_shard_row_stride(tfr_model* m);
 int tfr_shard_route(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate, int64_t batch_global,
                     int32_t rank, int32_t world, int64_t user_num_global, int64_t item_num_global,
                     int32_t sample_cap, int32_t slot_cap, int32_t* d_req /* out [world * slot_cap] */);
+/* the same routing with the global batch given as rows d_ids[0..batch_global) of this rank's copy of the rating store
+ * (tfr_upload_triples / tfr_set_triples_dev with GLOBAL user / item ids): the ShuffleIterator gather (dataio.py:115-117)
+ * happens inside the routing kernels and only the samples this rank owns leave the store. */
+int tfr_shard_route_ids(tfr_model* m, const int64_t* d_ids, int64_t batch_global, int32_t rank, int32_t world,
+                        int64_t user_num_global, int64_t item_num_global, int32_t sample_cap, int32_t slot_cap, int32_t* d_req);
 /* the routed batch, for the caller's bookkeeping and for tests: mine[sample_cap] global batch positions (-1 unused),
  * u_local[sample_cap], slot[sample_cap], counts = {local samples, distinct items, distinct items per owner [world]} */
 int tfr_shard_routed_devptrs(tfr_model* m, void** mine, void** u_local, void** slot, void** counts);

@@ -51,6 +51,14 @@ class OracleShard(object):
                        counts=torch.from_numpy(np.concatenate([[n, uq.size], cnt]).astype(np.int32)))
         return torch.from_numpy(req)
 
+    def set_store(self, u, i, r):
+        self._store = (u.clone(), i.clone(), r.clone())
+
+    def route_ids(self, ids, rank, world, U, I, sample_cap, slot_cap):
+        su, si, sr = self._store
+        sel = ids.long()
+        return self.route(su[sel], si[sel], sr[sel], rank, world, U, I, sample_cap, slot_cap)
+
     def routed(self):
         return dict(mine=self._r["mine"], u_local=self._r["u_local"], slot=self._r["slot_t"], counts=self._r["counts"])
 

@@ -103,6 +103,20 @@ def test_device_routing_is_bit_exact_against_numpy():
             g, w = hip.routed(), ora.routed()
             for k in ("counts", "mine", "u_local", "slot"):
                 assert np.array_equal(g[k].cpu().numpy(), w[k].numpy()), (k, U, I, world, rank)
+            # the same global batch as rows of a rating store the rank holds (tfr_shard_route_ids): same routing, bit for bit
+            Ns = Bg + 1000
+            ids = rs.permutation(Ns)[:Bg].astype(np.int64)
+            su = rs.randint(0, U, Ns).astype(np.int32); si = rs.randint(0, I, Ns).astype(np.int32)
+            sr = rs.randint(1, 6, Ns).astype(np.float32)
+            su[ids], si[ids], sr[ids] = u, i, r
+            keep = [torch.from_numpy(x).to(dev) for x in (su, si, sr)]
+            hip.set_store(*keep)
+            got2 = hip.route_ids(torch.from_numpy(ids).to(dev), rank, world, U, I, sample_cap, slot_cap)
+            hip.sync()
+            assert np.array_equal(got2.cpu().numpy(), want_req.numpy()), ("ids", U, I, world, rank)
+            g = hip.routed()
+            for k in ("counts", "mine", "u_local", "slot"):
+                assert np.array_equal(g[k].cpu().numpy(), w[k].numpy()), ("ids", k, U, I, world, rank)
             hip.model.close()
 
 

@@ -36,11 +36,21 @@ def _worker(rank, world, port, kw, U, I, D, B, steps):
         comm = sharded.Comm()
         m = sharded.ShardedSvd(U, I, D, comm, lambda ur, ir, d: OracleShard(ur, ir, d, **kw))
         m.set_tables_from_global(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        # every other step takes its global batch as rows of a rating store each rank holds a copy of (train_step_ids)
+        Ns = 3 * B + 7
+        su, si = dup_heavy_ids(rs, U, Ns), dup_heavy_ids(rs, I, Ns)
+        sr = (rs.rand(Ns) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, Ns).astype(np.float32)
+        m.backend.set_store(torch.from_numpy(su), torch.from_numpy(si), torch.from_numpy(sr))
         for s in range(steps):
-            u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
-            r = (rs.rand(B) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, B).astype(np.float32)
-            tu, ti, tr = torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(r)
-            logits, mine, scal = m.train_step(tu, ti, tr)
+            if s % 2:
+                ids = rs.randint(0, Ns, B)
+                u, i, r = su[ids], si[ids], sr[ids]
+                logits, mine, scal = m.train_step_ids(torch.from_numpy(ids))
+            else:
+                u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
+                r = (rs.rand(B) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, B).astype(np.float32)
+                tu, ti, tr = torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(r)
+                logits, mine, scal = m.train_step(tu, ti, tr)
             want_logits, want_loss, want_reg = ref.train_step(u, i, r)
             # ---- routing: integer work, exact
             p = m.backend.routed()

@@ -2096,12 +2096,11 @@ static int shard_stride(const tfr_model* m) { return m->VEC == 4 ? m->D + 4 : m-
 
 int32_t tfr_shard_row_stride(tfr_model* m) { return m ? shard_stride(m) : 0; }
 
-int tfr_shard_route(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate, int64_t Bg,
-                    int32_t rank, int32_t world, int64_t U_global, int64_t I_global, int32_t sample_cap, int32_t slot_cap,
-                    int32_t* d_req) {
-    MODEL_ENTER(m);
+static int shard_route_core(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate, const int64_t* d_ids,
+                            int64_t Bg, int32_t rank, int32_t world, int64_t U_global, int64_t I_global, int32_t sample_cap,
+                            int32_t slot_cap, int32_t* d_req) {
     if (Bg < 0 || world < 1 || rank < 0 || rank >= world || sample_cap < 1 || slot_cap < 1 || !d_req || U_global < 1 || I_global < 1 ||
-        I_global >= 0x7fffffffLL || U_global >= 0x7fffffffLL || (Bg > 0 && (!d_user || !d_item || !d_rate)))
+        I_global >= 0x7fffffffLL || U_global >= 0x7fffffffLL || (Bg > 0 && !d_ids && (!d_user || !d_item || !d_rate)))
         return fail(TFR_ERR_ARG, "shard_route: bad arguments");
     if ((int64_t)world * slot_cap >= 0x7fffffffLL) return fail(TFR_ERR_ARG, "shard_route: world * slot_cap too large");
     int rc;
@@ -2121,6 +2120,7 @@ int tfr_shard_route(tfr_model* m, const int32_t* d_user, const int32_t* d_item, 
     RouteArgs a;
     memset(&a, 0, sizeof(a));
     a.u = d_user; a.it = d_item; a.r = d_rate; a.Bg = Bg; a.U = U_global; a.I = I_global;
+    if (d_ids) { a.ids = d_ids; a.store = m->store; a.N = m->N; }
     a.per_u = (U_global + world - 1) / world; a.per_i = (I_global + world - 1) / world; a.u_lo = a.per_u * rank;
     a.rank = rank; a.world = world; a.Bcap = sample_cap; a.cap = slot_cap;
     a.u_pad = (int32_t)m->U; a.i_pad = (int32_t)I_global;
@@ -2140,6 +2140,21 @@ int tfr_shard_route(tfr_model* m, const int32_t* d_user, const int32_t* d_item, 
     launch_route_slots(a, s);
     HIPCHK(hipGetLastError());
     return TFR_OK;
+}
+
+int tfr_shard_route(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate, int64_t Bg,
+                    int32_t rank, int32_t world, int64_t U_global, int64_t I_global, int32_t sample_cap, int32_t slot_cap,
+                    int32_t* d_req) {
+    MODEL_ENTER(m);
+    return shard_route_core(m, d_user, d_item, d_rate, nullptr, Bg, rank, world, U_global, I_global, sample_cap, slot_cap, d_req);
+}
+
+int tfr_shard_route_ids(tfr_model* m, const int64_t* d_ids, int64_t Bg, int32_t rank, int32_t world, int64_t U_global,
+                        int64_t I_global, int32_t sample_cap, int32_t slot_cap, int32_t* d_req) {
+    MODEL_ENTER(m);
+    if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples / tfr_set_triples_dev first (global row ids)");
+    if (Bg > 0 && !d_ids) return fail(TFR_ERR_ARG, "shard_route_ids: null ids");
+    return shard_route_core(m, nullptr, nullptr, nullptr, d_ids, Bg, rank, world, U_global, I_global, sample_cap, slot_cap, d_req);
 }
 
 int tfr_shard_routed_devptrs(tfr_model* m, void** mine, void** u_local, void** slot, void** counts) {

@@ -31,21 +31,36 @@ __device__ __forceinline__ int block_rank_1024(bool flag, int* total) {
     return before + r;
 }
 
-__device__ __forceinline__ bool route_mine(const RouteArgs& a, int64_t k, bool* bad) {
+// sample k of the global batch: columns u / it / r, or (ids != NULL) row ids[k] of the rank's copy of the rating store -
+// the fused ShuffleIterator gather, as in the single-GPU step: only the samples a rank owns ever leave the store as columns
+__device__ __forceinline__ bool route_sample(const RouteArgs& a, int64_t k, int32_t* u, int32_t* it, float* r, bool* bad, bool* bad_id) {
+    if (a.ids) {
+        int64_t id = a.ids[k];
+        if ((uint64_t)id >= (uint64_t)a.N) { *bad_id = true; return false; }
+        const int4 rec = a.store[id];
+        *u = rec.x; *it = rec.y; *r = __int_as_float(rec.z);
+    } else {
+        *u = a.u[k]; *it = a.it[k]; *r = a.r[k];
+    }
+    if ((uint64_t)(int64_t)*u >= (uint64_t)a.U || (uint64_t)(int64_t)*it >= (uint64_t)a.I) { *bad = true; return false; }
+    return true;
+}
+__device__ __forceinline__ bool route_mine(const RouteArgs& a, int64_t k, bool* bad, bool* bad_id, int32_t* u, int32_t* it, float* r) {
     if (k >= a.Bg) return false;
-    const int64_t u = a.u[k], it = a.it[k];
-    if ((uint64_t)u >= (uint64_t)a.U || (uint64_t)it >= (uint64_t)a.I) { *bad = true; return false; }
-    return u / a.per_u == a.rank;
+    if (!route_sample(a, k, u, it, r, bad, bad_id)) return false;
+    return (int64_t)*u / a.per_u == a.rank;
 }
 
 // phase 1a: per 1024-sample block, how many samples are this rank's (and the global range check)
 __global__ __launch_bounds__(1024) void k_route_count(RouteArgs a) {
-    bool bad = false;
-    const bool f = route_mine(a, (int64_t)blockIdx.x * 1024 + threadIdx.x, &bad);
+    bool bad = false, bad_id = false;
+    int32_t u, it; float r;
+    const bool f = route_mine(a, (int64_t)blockIdx.x * 1024 + threadIdx.x, &bad, &bad_id, &u, &it, &r);
     int tot;
     (void)block_rank_1024(f, &tot);
     if (threadIdx.x == 0) a.blk[blockIdx.x] = tot;
     if (bad) atomicOr(a.err, 1);
+    if (bad_id) atomicOr(a.err, 2);
 }
 
 // exclusive scan of blk[0..n) in place by ONE block (n <= a few thousand); total -> *out (clamped to limit, flagging overflow)
@@ -74,16 +89,17 @@ __global__ __launch_bounds__(1024) void k_route_scan(int32_t* blk, int n, int32_
 // phase 1b: the rank's samples, compacted in batch order; unused sample slots get keys that sort last
 __global__ __launch_bounds__(1024) void k_route_scatter(RouteArgs a) {
     const int64_t k = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    bool bad = false;
-    const bool f = route_mine(a, k, &bad);
+    bool bad = false, bad_id = false;
+    int32_t su = 0, sit = 0; float sr = 0.f;
+    const bool f = route_mine(a, k, &bad, &bad_id, &su, &sit, &sr);
     int tot;
     const int r = block_rank_1024(f, &tot);
     const int dst = a.blk[blockIdx.x] + r;
     if (f && dst < a.Bcap) {
         a.mine[dst] = (int32_t)k;
-        a.u_local[dst] = (int32_t)(a.u[k] - a.u_lo);
-        a.it_glob[dst] = a.it[k];
-        a.r_loc[dst] = a.r[k];
+        a.u_local[dst] = (int32_t)(su - a.u_lo);
+        a.it_glob[dst] = sit;
+        a.r_loc[dst] = sr;
     }
     // the tail [n_local, Bcap): every block pads a stripe of it
     const int n_local = a.counts[0];

@@ -229,6 +229,7 @@ void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hip
 // the distinct item rows they need, grouped by owner into a fixed-capacity request layout [world][cap]
 struct RouteArgs {
     const int32_t* u; const int32_t* it; const float* r;     // the GLOBAL batch [Bg], identical on every rank
+    const int64_t* ids; const int4* store; int64_t N;        // or (ids != NULL): rows ids[0..Bg) of the rank's copy of the rating store
     int64_t Bg, U, I;                                        // global row counts (range check)
     int64_t per_u, per_i, u_lo;                              // block partition: owner = id / per
     int32_t rank, world, Bcap, cap;                          // capacities: local samples, request slots per owner

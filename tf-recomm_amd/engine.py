@@ -287,6 +287,10 @@ class SvdModel:
         L.check(self._lib.tfr_shard_route(self._h, d_user, d_item, d_rate, batch_global, rank, world, user_num_global,
                                           item_num_global, sample_cap, slot_cap, d_req))
 
+    def shard_route_ids(self, d_ids, batch_global, rank, world, user_num_global, item_num_global, sample_cap, slot_cap, d_req):
+        L.check(self._lib.tfr_shard_route_ids(self._h, d_ids, batch_global, rank, world, user_num_global, item_num_global,
+                                              sample_cap, slot_cap, d_req))
+
     def shard_routed_devptrs(self):
         ps = [L._p() for _ in range(4)]
         L.check(self._lib.tfr_shard_routed_devptrs(self._h, *[C.byref(p) for p in ps]))
