@@ -40,6 +40,7 @@ struct RedArgs {
     float* own_w; float* m; float* v; float* bias_w; float* bias_m; float* bias_v;
     float* grad_rows; float* grad_bias; int32_t* map;
     float* dense_rows; float* dense_bias;          // optional dense [rows,D] / [rows] gradient buffers
+    int32_t dstride, dbstride;                     // their row / bias strides in floats (0 = D / 1): the packed exchange layout
     const float* rows_in; const float* bias_in;    // sharded owner side: pre-reduced gradient rows
     const float* lam_arr;                          // optional per-entry coefficient of the own row (FM)
     float* own_copy_out;                           // optional [B,D]: the entry's pre-update own row, by batch position

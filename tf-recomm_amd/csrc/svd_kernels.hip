@@ -1035,8 +1035,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     if (RMODE == RMODE_SCRATCH && whole && a.dense_rows) {
         // dense-gradient form (TF1 Adam sweep / data parallel): a run that lies in one block goes
         // straight to its row of the dense buffer - the consumer streams it with no indirection
-        store_frag<VEC>(a.dense_rows + roff, d0, D, acc);
-        if (gl == 0) a.dense_bias[row] = gb;
+        store_frag<VEC>(a.dense_rows + (a.dstride ? (size_t)row * a.dstride : roff), d0, D, acc);
+        if (gl == 0) a.dense_bias[a.dbstride ? (size_t)row * a.dbstride : (size_t)row] = gb;
     } else if (RMODE == RMODE_SCRATCH || !whole) {
         store_frag<VEC>(a.grad_rows + (size_t)j * D, d0, D, acc);
         if (gl == 0) {
