@@ -2196,19 +2196,9 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
     hipStream_t s = m->stream;
     int nblk = 0;
     {
-        FwdArgs f;
-        memset(&f, 0, sizeof(f));
-        f.P = m->w[TFR_P]; f.Q = d_item_rows; f.bu = m->w[TFR_BU]; f.bi = d_item_rows + m->D; f.mu = m->w[TFR_MU];
-        f.qstride = DS; f.bistride = DS; f.dB = dB;
-        f.u = du; f.it = dslot; f.r = dr; f.logits = d_logits; f.g = m->d_g; f.partials = m->partials; f.err = m->d_err;
-        f.B = B; f.U = m->U; f.I = nI;
-        f.D = m->D; f.loss = o.loss; f.item_abs = o.item_abs; f.reg_bias = o.reg_bias;
-        nblk = forward_grid(B, m->G, MODE_TRAIN);
-        {
-            Prof p(m, TFR_K_FORWARD);
-            launch_forward(f, MODE_TRAIN, m->G, m->VEC, nblk, s);
-        }
-        HIPCHK(hipGetLastError());
+        // K1 runs inside the item-side reduce, on the rows it has in registers anyway (as in the single-GPU big-table step);
+        // a separate k_forward launch cost 68 us of the 464 (world-1 rehearsal)
+        nblk = (int)((B + 1024 / m->G - 1) / (1024 / m->G));
         {
             Prof p(m, TFR_K_SORT);                        // unused sample slots carry keys one past the last row: they sort last
             const int32_t* keys[2] = {du, dslot};
@@ -2231,10 +2221,12 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
         // a slot whose samples lie in one block of the sorted order (nearly all) goes straight into the exchange buffer;
         // k_apply_rows then only finishes the slots cut by a block boundary (it emitted every slot before: 102 us)
         ri.dense_rows = d_item_grad; ri.dstride = DS; ri.dense_bias = d_item_grad + m->D; ri.dbstride = DS;
+        ri.partner_bias = m->w[TFR_BU]; ri.mu = m->w[TFR_MU]; ri.r = dr; ri.loss = o.loss;
+        ri.g_out = m->d_g; ri.logits_out = d_logits; ri.partials = m->partials; ri.stage_sum = 1;
         pr.a[0] = ri;
         {
             Prof p(m, TFR_K_REDUCE_ITEM);
-            launch_seg_reduce(pr, 1, RMODE_SCRATCH, m->G, m->VEC, s);
+            launch_seg_reduce(pr, 1, RMODE_SCRATCH, m->G, m->VEC, s, true);
         }
         HIPCHK(hipGetLastError());
         ApplyArgs ap;

@@ -901,7 +901,12 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         prev = (j > 0) ? a.ks[j - 1] : -2;
         pos = a.ps[j];
     }
-    if (err || blk0 >= Bn) return;           // an out-of-range id voids the whole step (block-uniform)
+    if (err || blk0 >= Bn) {                 // an out-of-range id voids the whole step (block-uniform)
+        // a grid sized for a capacity (row-sharded step: the entry count lives on the device): the blocks past the
+        // entries still owe K4 their - empty - partial sums
+        if constexpr (FWD) { if (!err && a.dB && threadIdx.x < 4) a.partials[(size_t)blockIdx.x * 4 + threadIdx.x] = 0.f; }
+        return;
+    }
     // tile mode: the sorted order is per 1024-entry tile, so a run also starts at every tile start
     const bool head = valid && (prev != row || (a.tile && (j % a.tile) == 0));
     const bool pstart = valid && (head || grp == 0);
@@ -1693,6 +1698,7 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
     if (G == g && VEC == v) {                                                                          \
         if (fwd && rmode == RMODE_ADAM && !lean) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, false>), grid, dim3(1024), 0, s, p); \
         else if (fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true>), grid, dim3(1024), 0, s, p); \
+        else if (fwd && rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH, true>), grid, dim3(1024), 0, s, p); \
         else if (fwd) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD, true>), grid, dim3(1024), 0, s, p); \
         else if (rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH>), grid, dim3(1024), 0, s, p); \
         else if (rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM>), grid, dim3(1024), 0, s, p);  \
