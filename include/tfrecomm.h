@@ -165,6 +165,12 @@ int tfr_rng_set_state(tfr_model* m, const uint32_t* key624, int32_t pos);    /* 
 int tfr_rng_get_state(tfr_model* m, uint32_t* key624, int32_t* pos);         /* synchronises */
 /* ids_out[count] (host) = np.random.randint(0, high, (count,)); advances the device state. */
 int tfr_draw_ids(tfr_model* m, int64_t high, int64_t count, int64_t* ids_out);
+/* the same draw into DEVICE memory, asynchronously on the draw stream: it starts once everything queued on the model's
+ * stream so far has finished (which may still read d_ids_out), and tfr_join_draws makes the model's stream wait for every
+ * draw issued so far.  For callers that run the step themselves, one call at a time (the data-parallel loop: every rank
+ * draws the global batch's ids - the same stream on every rank - and takes its slice, dataio.py:115 with no host in it). */
+int tfr_draw_ids_dev(tfr_model* m, int64_t high, int64_t count, int64_t* d_ids_out);
+int tfr_join_draws(tfr_model* m);
 /* nsteps x { next(iter_train); sess.run(train_op) } (svd_train_val.py:66-72) with every part on the
  * device: ids drawn from randint(0, n_store_ratings) as above (on a side stream, ahead of the steps
  * that use them), rows gathered from the resident store, one training step each.  loss_out[nsteps]

@@ -58,6 +58,31 @@ def test_draw_matches_numpy_and_leaves_numpy_state(model):
     assert np.array_equal(np.random.randint(0, 999, 100), m.draw_ids(999, 100))
 
 
+def test_draw_into_device_memory_and_join(model):
+    """tfr_draw_ids_dev / tfr_join_draws (the data-parallel loop's feed): asynchronous draws into caller-owned device
+    buffers, the same stream and final state as NumPy; a buffer is only overwritten after the work queued before the call."""
+    import torch
+    m = model
+    np.random.seed(99)
+    m.rng_seed(99)
+    bufs = [torch.empty(70000, dtype=torch.int64, device="cuda") for _ in range(3)]
+    want = []
+    for k, (high, count) in enumerate(((900188, 20000), (900188, 70000), (50, 1), (1 << 20, 40000), (1, 5))):
+        want.append(np.random.randint(0, high, (count,)))
+        m.draw_ids_dev(high, count, bufs[k % 3].data_ptr())
+        if k % 3 == 2 or k == 4:
+            m.join_draws()
+            m.sync()
+            torch.cuda.synchronize()
+            for q in range(k - (k % 3), k + 1):
+                assert np.array_equal(bufs[q % 3][: want[q].size].cpu().numpy(), want[q]), q
+    key, pos = m.rng_get_state()
+    st = np.random.get_state()
+    assert pos == st[2] and np.array_equal(key, st[1])
+    with pytest.raises(T.TfrError):
+        m.draw_ids_dev(0, 5, bufs[0].data_ptr())
+
+
 def test_wide_draw_that_comes_up_short_is_finished_by_the_sequential_kernel():
     """TFR_RNG_WIDE_TRIM makes the wide form generate too few blocks: the k_mt_draw launch behind it draws the rest from
     the state the last block left - same ids, same final state (a fresh process: the switch is read once)."""

@@ -87,6 +87,7 @@ struct tfr_model {
     int64_t alt_cap = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_first = nullptr;
+    hipEvent_t draw_ev = nullptr; bool draw_pending = false;   // tfr_draw_ids_dev / tfr_join_draws
     MtScratch rng_ws = {nullptr, nullptr, nullptr, 0};     // wide form of the id draw (rng.hip), allocated with the generator state
     hipEvent_t ev_mid = nullptr; bool ev_mid_on = false;   // recorded between the item-side and the user-side kernel of a big-table step
     // resident store
@@ -367,6 +368,7 @@ int tfr_destroy(tfr_model* m) {
     for (int z = 0; z < 2; ++z) { if (m->ev_sorted[z]) (void)hipEventDestroy(m->ev_sorted[z]); if (m->ev_free[z]) (void)hipEventDestroy(m->ev_free[z]); }
     if (m->ev_first) (void)hipEventDestroy(m->ev_first);
     if (m->ev_mid) (void)hipEventDestroy(m->ev_mid);
+    if (m->draw_ev) (void)hipEventDestroy(m->draw_ev);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
     return TFR_OK;
@@ -1872,6 +1874,38 @@ int tfr_draw_ids(tfr_model* m, int64_t high, int64_t count, int64_t* ids_out) {
     dfree(dbg);
     dfree(d);
     if (e != hipSuccess) return fail(TFR_ERR_HIP, "draw_ids: %s", hipGetErrorString(e));
+    return TFR_OK;
+}
+
+int tfr_draw_ids_dev(tfr_model* m, int64_t high, int64_t count, int64_t* d_ids_out) {
+    MODEL_ENTER(m);
+    int rc;
+    if ((rc = check_high(high))) return rc;
+    if (count < 0 || (count > 0 && !d_ids_out)) return fail(TFR_ERR_ARG, "draw_ids_dev: bad count / null output");
+    if (!m->rng_set) return fail(TFR_ERR_STATE, "no generator state: call tfr_rng_seed / tfr_rng_set_state first");
+    if (count == 0) return TFR_OK;
+    if ((rc = cancel_run_ahead(m))) return rc;
+    if (!m->draw_ev) HIPCHK(hipEventCreateWithFlags(&m->draw_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));     // the buffer's readers queued so far
+    HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));
+    if (high == 1) {                                       // rng == 0: no draw is consumed
+        HIPCHK(hipMemsetAsync(d_ids_out, 0, (size_t)count * 8, m->stream3));
+    } else {
+        const uint32_t rng = (uint32_t)(high - 1);
+        launch_mt_draw(m->d_rng, d_ids_out, count, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(m->draw_ev, m->stream3));
+    m->draw_pending = true;
+    return TFR_OK;
+}
+
+int tfr_join_draws(tfr_model* m) {
+    MODEL_ENTER(m);
+    if (m->draw_pending) {
+        HIPCHK(hipStreamWaitEvent(m->stream, m->draw_ev, 0));
+        m->draw_pending = false;
+    }
     return TFR_OK;
 }
 

@@ -98,17 +98,36 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
     be = HipReplica(U, I, D, local_rank, optimizer="adam", adam_mode="tf1", lr=wl["lr"], reg=wl["reg"])
     be.model.init_tables(seed=13575)                   # counter-based initialiser: identical replicas
     be.model.upload_triples(*train)
-    np.random.seed(13575)                              # svd_train_val.py:15 - one global draw per step
-    ids = np.random.randint(0, len(train[0]), (W + K, world * B))
-    be.model.stage_ids(np.ascontiguousarray(ids[:, rank * B:(rank + 1) * B]))
-    base, _ = be.model.staged_ids_devptr()
+    # the id draw is inside the loop, as at N=1: every rank replays the ONE global stream np.random.seed(13575);
+    # randint(0, N, (world * B,)) per step (svd_train_val.py:15, dataio.py:115) on its own generator (rng.hip, side stream,
+    # eight steps' ids per draw, two draws ahead, three buffers) and takes its slice - no host draw, no id upload, no communication
+    ntrain = len(train[0])
+    np.random.seed(13575)
+    be.model.rng_from_numpy()
+    CH = 8                                             # steps per draw: one launch + two events per CH steps, not per step
+    Bg = world * B
+    ids_buf = torch.empty((3, CH * Bg), dtype=torch.int64, device=dev)
     dp = DataParallelSvd(be)
     stage = dp.stage
     torch.cuda.set_stream(be.stream)                   # the collective queues behind the model's kernels
+    issued = [0]
 
-    def step(s):
-        dp.train_step(store_ids_ptr=base + s * B * 8, batch=B, want_scalars=False,
-                      next_ids_ptr=base + (s + 1) * B * 8 if s + 1 < W + K else None)
+    def issue():                                       # chunk c = the ids of steps [c * CH, (c + 1) * CH)
+        be.model.draw_ids_dev(ntrain, CH * Bg, ids_buf[issued[0] % 3].data_ptr())
+        issued[0] += 1
+    issue(); issue()
+    done = [0]
+
+    def ids_ptr(s):
+        return ids_buf[(s // CH) % 3].data_ptr() + ((s % CH) * Bg + rank * B) * 8
+
+    def step(_s):
+        s = done[0]
+        if s % CH == 0:
+            be.model.join_draws()                      # chunks s / CH and s / CH + 1 (issued one and two chunks ago)
+            issue()                                    # chunk s / CH + 2: into the buffer chunk s / CH - 1 lived in
+        dp.train_step(store_ids_ptr=ids_ptr(s), batch=B, want_scalars=False, next_ids_ptr=ids_ptr(s + 1))
+        done[0] += 1
     # untimed set-up before the W warm-up steps: the first few dozen collectives of a process pay one-off costs (RCCL channel
     # and buffer set-up, allocator growth - a single 40 ms stall was seen between steps 10 and 20 of the row-sharded loop);
     # they are paid here, on the first batches, and not inside a short timed region
@@ -135,9 +154,13 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
     n_t = min(K, 20)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_t)]
     for k in range(n_t):
-        s = W + (k % K)
+        s = done[0]
+        if s % CH == 0:
+            be.model.join_draws()
+            issue()
         ev[k][0].record()
-        flat = be.local_grads(None, None, None, base + s * B * 8, B)
+        flat = be.local_grads(None, None, None, ids_ptr(s), B)
+        done[0] += 1
         ev[k][1].record()
         dp._all_reduce(flat)
         ev[k][2].record()
@@ -159,7 +182,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
                 dtype="f32", data="synthetic",
                 config=dict(workload="%s: %s" % (workload_key, wl["name"]), untimed_setup_steps=SETUP_STEPS if W < SETUP_STEPS else 0, users=U, items=I, dim=D, global_batch=B * world, per_gpu_batch=B,
                             optimizer="adam", adam_mode="tf1", lr=wl["lr"], reg=wl["reg"],
-                            id_stream="np.random.seed(13575); randint(0, N, (world * B,)) per step, each rank takes its slice (pre-staged)",
+                            id_stream="np.random.seed(13575); randint(0, N, (world * B,)) per step, drawn inside the timed loop by every rank's own generator (same stream), each rank takes its slice",
                             parallelism="dp%d: replicated tables, one %.1f MB gradient all-reduce (RCCL) per step"
                                         % (world, nbytes / 1e6)),
                 val_rmse=float(np.sqrt(sse / len(val[0]))),

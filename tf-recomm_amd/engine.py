@@ -248,6 +248,14 @@ class SvdModel:
         L.check(self._lib.tfr_draw_ids(self._h, int(high), out.size, L.ptr_i64(out)))
         return out
 
+    def draw_ids_dev(self, high, count, d_out):
+        """``np.random.randint(0, high, (count,))`` into device memory (pointer), asynchronously on the draw stream"""
+        L.check(self._lib.tfr_draw_ids_dev(self._h, int(high), int(count), d_out))
+
+    def join_draws(self):
+        """the model's stream waits for every draw issued by ``draw_ids_dev`` so far"""
+        L.check(self._lib.tfr_join_draws(self._h))
+
     def train_steps_drawn(self, batch, nsteps, want_loss=False):
         """nsteps x { next(iter_train); sess.run(train_op) } with the id draw, the gather from the resident
         store and the step all on the device."""
