@@ -76,6 +76,7 @@ struct tfr_model {
     // host-fed calls (tfr_train_step / tfr_forward): one pinned staging buffer each way, so a step is one
     // H2D copy, the kernels and one D2H copy instead of five pageable transfers
     int32_t* d_in = nullptr; int32_t* h_in = nullptr; float* h_out = nullptr; int64_t stage_cap = 0;
+    int32_t* h_err = nullptr;                                // pinned landing place of the device error flag
     // look-ahead of the small-table step: the next batch's tile sort, published by the previous launch
     int4* srt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [parity][side] sorted records {u, i, r, pos}
     const int64_t* pf_ids = nullptr; int64_t pf_B = 0; int pf_par = 0; bool pf_valid = false;
@@ -197,6 +198,8 @@ static void free_workspace(tfr_model* m) {
     dfree(m->d_in); m->d_in = nullptr;
     if (m->h_in) (void)hipHostFree(m->h_in);
     if (m->h_out) (void)hipHostFree(m->h_out);
+    if (m->h_err) (void)hipHostFree(m->h_err);
+    m->h_err = nullptr;
     m->h_in = nullptr; m->h_out = nullptr; m->stage_cap = 0;
     dfree(m->alt.d_u); dfree(m->alt.d_i); dfree(m->alt.d_r); dfree(m->alt.ks_u); dfree(m->alt.ps_u); dfree(m->alt.ks_i); dfree(m->alt.ps_i);
     m->alt = tfr_model::SortSet(); m->alt_cap = 0;
@@ -285,9 +288,12 @@ static int ensure_step_out(tfr_model* m, int64_t nsteps) {
 
 // read + clear the device error flag (stream must be idle or this call synchronises)
 static int check_device_error(tfr_model* m) {
-    int32_t e = 0;
-    HIPCHK(hipMemcpyAsync(&e, m->d_err, sizeof(e), hipMemcpyDeviceToHost, m->stream));
+    // the flag lands in pinned memory: a pageable destination turns the 4-byte copy into a staged, blocking one
+    if (!m->h_err) HIPCHK(hipHostMalloc((void**)&m->h_err, 64, hipHostMallocDefault));
+    *m->h_err = 0;
+    HIPCHK(hipMemcpyAsync(m->h_err, m->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
+    const int32_t e = *m->h_err;
     if (e) {
         HIPCHK(hipMemsetAsync(m->d_err, 0, sizeof(int32_t), m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
