@@ -98,14 +98,17 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
     be = HipReplica(U, I, D, local_rank, optimizer="adam", adam_mode="tf1", lr=wl["lr"], reg=wl["reg"])
     be.model.init_tables(seed=13575)                   # counter-based initialiser: identical replicas
     be.model.upload_triples(*train)
-    # the id draw is inside the loop, as at N=1: every rank replays the ONE global stream np.random.seed(13575);
-    # randint(0, N, (world * B,)) per step (svd_train_val.py:15, dataio.py:115) on its own generator (rng.hip, side stream,
-    # eight steps' ids per draw, two draws ahead, three buffers) and takes its slice - no host draw, no id upload, no communication
+    # the id draw is inside the loop, as at N=1: rank r draws ITS B ids per step with np.random.seed(13575 + r);
+    # randint(0, N, (B,)) (svd_train_val.py:15, dataio.py:115; rank 0 = the reference's own stream) on the device generator
+    # (rng.hip, side stream, eight steps' ids per draw, two draws ahead, three buffers) - no host draw, no id upload, no
+    # communication.  One global stream cut into slices would make every rank generate all N * B ids per step (MT19937
+    # cannot skip ahead cheaply): 52 us per step at N = 8, the next bound after the all-reduce; independent streams keep
+    # the draw at 1/N of that.  The reference has no multi-GPU definition to follow (README.md:10).
     ntrain = len(train[0])
-    np.random.seed(13575)
+    np.random.seed(13575 + rank)
     be.model.rng_from_numpy()
     CH = 8                                             # steps per draw: one launch + two events per CH steps, not per step
-    Bg = world * B
+    Bg = B                                             # ids this rank draws per step
     ids_buf = torch.empty((3, CH * Bg), dtype=torch.int64, device=dev)
     dp = DataParallelSvd(be)
     stage = dp.stage
@@ -119,7 +122,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
     done = [0]
 
     def ids_ptr(s):
-        return ids_buf[(s // CH) % 3].data_ptr() + ((s % CH) * Bg + rank * B) * 8
+        return ids_buf[(s // CH) % 3].data_ptr() + (s % CH) * Bg * 8
 
     def step(_s):
         s = done[0]
@@ -182,7 +185,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
                 dtype="f32", data="synthetic",
                 config=dict(workload="%s: %s" % (workload_key, wl["name"]), untimed_setup_steps=SETUP_STEPS if W < SETUP_STEPS else 0, users=U, items=I, dim=D, global_batch=B * world, per_gpu_batch=B,
                             optimizer="adam", adam_mode="tf1", lr=wl["lr"], reg=wl["reg"],
-                            id_stream="np.random.seed(13575); randint(0, N, (world * B,)) per step, drawn inside the timed loop by every rank's own generator (same stream), each rank takes its slice",
+                            id_stream="rank r: np.random.seed(13575 + r); randint(0, N, (B,)) per step, drawn inside the timed loop on the device",
                             parallelism="dp%d: replicated tables, one %.1f MB gradient all-reduce (RCCL) per step"
                                         % (world, nbytes / 1e6)),
                 val_rmse=float(np.sqrt(sse / len(val[0]))),
