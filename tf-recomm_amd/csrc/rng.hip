@@ -193,7 +193,9 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_draw(uint32_t* __restrict__ s
 // ---- the wide form, for draws of tens of thousands of ids and more ----------------------------------------------------
 // Measured (one gpurun call, TFR_RNG_WIDE=0/1): 262144 ids of a 99M store 326 -> 214 us; the C3-shaped step at dim 32, which the
 // draw bounds, 330 -> 235 us; the headline step (chunks of up to 60000 ids) 20.2 -> 19.5 us.  What is left is the recurrence
-// itself: ~900 cycles per 624-word block for ten waves in lock step on one CU (LDS round trip + ~35 instructions + barrier).
+// itself: ~700-900 cycles per 624-word block for ten waves in lock step on one CU (LDS round trip + ~35 instructions + barrier).
+// Five waves with two words each and one masked three-term form for every lane (no per-wave branches) are slower: 0.383 against
+// 0.295 us per block (tools/probes/mt_blocks.hip, same words out).
 // k_mt_draw does everything on one CU and is bound by its instruction count (~1500 cycles per 624 words).  Only the
 // recurrence itself is sequential: k_mt_blocks runs it alone (one LDS round trip, ~40 instructions and one barrier per
 // block) and writes the raw blocks to memory; tempering, the rejection test and the compaction are then ordinary
