@@ -79,6 +79,13 @@ def test_session_fork_style_nll():
         nll = sess.run(cost_nll, feed_dict={rb: r, logits: lg})               # svd_train_val.py:94
         assert_close(nll, wloss, rtol=1e-5)
         assert_close(sess.run(user_features), orc.P, rtol=2 * RTOL)
+        # the handles are the gathered embeddings (ops.py:13-14,37-38): fed ids select rows, adaptive_test.py:42-44 style
+        allu = sess.run(user_features, feed_dict={ub: range(U)})
+        assert allu.shape == (U, D) and np.array_equal(allu, sess.run(user_features))
+        some_u, some_i = np.array([5, 5, 0, 59]), np.array([49, 1])
+        got_pu, got_bu, got_q = sess.run([user_features, user_bias, item_features], feed_dict={ub: some_u, ib: some_i})
+        assert np.array_equal(got_pu, allu[some_u]) and got_bu.shape == (4,) and got_q.shape == (2, D)
+        assert_close(got_q, orc.Q[some_i], rtol=2 * RTOL)
 
 
 def test_svd_driver_prints_reference_rows_and_learns(tmp_path):

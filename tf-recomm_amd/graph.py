@@ -222,7 +222,13 @@ class Session(object):
         out = []
         for f, k in zip(flist, kinds):
             if k == "variable":
-                out.append(m.get_table(f.table))
+                # the handles ops.inference_svd returns for the embeddings are the GATHERED tensors (ops.py:13-14,37-38:
+                # embedding_lookup of the fed ids) - adaptive_test.py:42-44 fetches them with user_batch: range(USER_NUM);
+                # without the id feed (or for bias_global) the whole variable comes back.  With train_op in the same run
+                # the rows are read after the step.
+                tab = m.get_table(f.table)
+                ids = feeds.get("user") if f.table in (L.BU, L.P) else feeds.get("item") if f.table in (L.BI, L.Q) else None
+                out.append(tab if ids is None else tab[L.as_i32(ids, "ids")])
             elif k == "global_step":
                 out.append(m.step)
             elif k in ("train_op", "noop", "group", "init"):
