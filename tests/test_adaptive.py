@@ -183,3 +183,47 @@ def test_drivers_on_the_hip_path_match_the_oracle(opt, tol):
         assert g["asked"] == w["asked"] and g["outcome"] == w["outcome"]
         assert_close(g["predicted"], w["predicted"], rtol=tol, what="predictions of user %d" % g["user"])
         assert abs(g["mcost"] - w["mcost"]) <= tol * max(1.0, abs(w["mcost"]))
+
+
+@pytest.mark.gpu
+def test_a_loop_spelled_like_non_adaptive_test_gives_the_drivers_numbers():
+    """The reference's own spelling of the loop (non_adaptive_test.py:20-31,36-37,56-87: placeholders, the fork's
+    inference_svd / optimization with var_list=[user_bias, user_features], one sess.run per epoch) through the Session
+    mirror, against tfrecomm_amd.adaptive_test.non_adaptive_test on an identical model: same predictions bit for bit (the
+    driver's one-call inner loop is the same arithmetic), item tables untouched."""
+    from tfrecomm_amd import graph as tf, ops
+    U, I, D, EPOCH_MAX = 30, 40, 8, 12
+    rs = np.random.RandomState(3)
+    t = rand_tables(rs, U, I, D)
+    df = _frame(rs, U, I, 25, binary=True)
+    tf.reset_default_graph()
+    user_batch = tf.placeholder(tf.int32, shape=[None], name="id_user")
+    item_batch = tf.placeholder(tf.int32, shape=[None], name="id_item")
+    rate_batch = tf.placeholder(tf.float32, shape=[None])
+    wins_batch = tf.placeholder(tf.float32, shape=[None], name="nb_wins")
+    fails_batch = tf.placeholder(tf.float32, shape=[None], name="nb_fails")
+    infer, logits, regularizer, user_bias, user_features, item_bias, item_features = ops.inference_svd(
+        user_batch, item_batch, wins_batch, fails_batch, user_num=U, item_num=I, dim=D, device="/cpu:0", fork_semantics=True)
+    tf.train.get_or_create_global_step()
+    cost, train_op = ops.optimization(infer, logits, regularizer, rate_batch, learning_rate=5e-3, reg=0.1, device="/cpu:0",
+                                      var_list=[user_bias, user_features])
+    preds = []
+    with tf.Session() as sess:
+        sess.run(tf.global_variables_initializer())
+        sess.model.set_tables(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        kw = dict(loss=sess.model.loss, item_abs=sess.model.item_abs, reg_bias=sess.model.reg_bias, optimizer=sess.model.optimizer,
+                  adam_mode=sess.model.adam_mode, lr=5e-3, reg=0.1)
+        hist = {}
+        for user_id, item_id, outcome in zip(df["user"], df["item"], df["outcome"]):
+            h = hist.setdefault(int(user_id), ([], [], []))
+            h[0].append(user_id); h[1].append(item_id); h[2].append(outcome)
+            item_logit = sess.run(logits, feed_dict={user_batch: [user_id], item_batch: [item_id], wins_batch: [0], fails_batch: [0]})
+            preds.append(float(ops.sigmoid(item_logit)[0]))
+            for _ in range(EPOCH_MAX):
+                sess.run([train_op, infer, user_bias, user_features], feed_dict={
+                    user_batch: h[0], item_batch: h[1], rate_batch: h[2], wins_batch: h[2], fails_batch: h[2]})
+        q_after = sess.run(item_features)
+    assert np.array_equal(q_after, t["Q"])
+    with _model(U, I, D, t, **kw) as m:
+        got = AT.non_adaptive_test(m, df, epoch_max=EPOCH_MAX)
+    assert got["pred"] == preds
