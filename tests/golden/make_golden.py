@@ -227,6 +227,12 @@ def part6():
     np.savez_compressed(os.path.join(HERE, "als_trajectory.npz"), **out)
 
 
+LEGEND_CASES = [dict(d=0, users=True, items=True), dict(d=5, users=True, items=True), dict(d=0, skills=True, attempts=True),
+                dict(d=0, skills=True, wins=True, fails=True), dict(d=20, users=True, items=True, skills=True, wins=True, fails=True),
+                dict(d=3, items=True, item_wins=True, item_fails=True, extra=True), dict(d=0), dict(d=7, skills=True, attempts=True),
+                dict(d=2, users=False, items=True, wins=True)]
+
+
 def part7():
     """CSV loaders pinned by the REAL reference readers (dataio.py:8-16,38-54): a small prepared-dataset folder
     (data written here - synthetic rows, not reference content) is read with the reference's own
@@ -246,6 +252,9 @@ def part7():
             f.write("%d\t%d\t%.1f\t0\t0\n" % (rs.randint(0, 40), rs.randint(0, 30), rs.randint(1, 6)))
     with open(os.path.join(folder, "config.yml"), "w") as f:
         f.write("USER_NUM: 40\nITEM_NUM: 30\nNB_CLASSES: 2\nBATCH_SIZE: 8\n")
+    with open(os.path.join(folder, "all.csv"), "w") as f:           # the FM experiments' single-file layout (dataio.py:19-28,57-60)
+        for _ in range(11):
+            f.write("%d,%d,%d,%d,%d\n" % (rs.randint(0, 40), rs.randint(0, 30), rs.randint(0, 2), rs.randint(0, 6), rs.randint(0, 6)))
     out = {}
     cwd = os.getcwd()
     os.chdir(root)                                                  # the reference's paths are relative: data/<name>/...
@@ -254,6 +263,16 @@ def part7():
         out["paths"] = np.array([p.replace(os.sep, "/") for p in paths])
         frames = dict(zip(("train", "val", "test"), ref_dataio.get_data("tiny")))
         frames["tabbed"] = ref_dataio.read_process(os.path.join("data", "tiny", "tabbed.tsv"))
+        out["new_paths"] = np.array([p.replace(os.sep, "/") for p in ref_dataio.build_new_paths("tiny")])
+        frames["all"] = ref_dataio.get_new_data("tiny")
+        import contextlib, io, json
+        legends = []
+        for args in LEGEND_CASES:                                   # dataio.py:63-87 (it prints; keep stdout clean)
+            with contextlib.redirect_stdout(io.StringIO()):
+                short, full, latex, active = ref_dataio.get_legend(dict(args))
+            legends.append([short, full, latex, list(active)])
+        out["legend_cases"] = np.array(json.dumps(LEGEND_CASES))
+        out["legends"] = np.array(json.dumps(legends))
     finally:
         os.chdir(cwd)
     for name, df in frames.items():

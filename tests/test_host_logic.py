@@ -85,7 +85,14 @@ def test_csv_loaders_match_the_reference_readers_frames(golden):
     assert [p.replace(os.sep, "/") for p in got_paths] == list(g["paths"])
     tr, va, te = dataio.get_data("tiny", data_folder=os.path.join(root, "data"))
     frames = {"train": tr, "val": va, "test": te,
-              "tabbed": dataio.read_process(os.path.join(root, "data", "tiny", "tabbed.tsv"))}
+              "tabbed": dataio.read_process(os.path.join(root, "data", "tiny", "tabbed.tsv")),
+              "all": dataio.get_new_data("tiny", data_folder=os.path.join(root, "data"))}      # dataio.py:57-60
+    assert [p.replace(os.sep, "/") for p in dataio.build_new_paths("tiny")] == list(g["new_paths"])   # dataio.py:19-28
+    import json
+    cases, want = json.loads(str(g["legend_cases"])), json.loads(str(g["legends"]))                # dataio.py:63-87
+    assert len(cases) == len(want) >= 9
+    for args, (short, full, latex, active) in zip(cases, want):
+        assert dataio.get_legend(args) == (short, full, latex, active), args
     for name, df in frames.items():
         assert list(df.columns) == list(g[name + "/columns"])
         for c in df.columns:

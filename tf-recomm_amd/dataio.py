@@ -129,6 +129,38 @@ def get_data(dataset_name, data_folder="data"):
     return read_process(csv_train, sep=","), read_process(csv_val, sep=","), read_process(csv_test, sep=",")
 
 
+def build_new_paths(dataset_name, data_folder="data"):
+    """data/<name>/{all.csv, config.yml, qmatrix.npz, skill_wins.npz, skill_fails.npz} - the single-file layout of the FM
+    experiments (dataio.py:19-28, read by fm.py:34 and sharedtask.py:24)."""
+    folder = os.path.join(data_folder, dataset_name)
+    return (folder,) + tuple(os.path.join(folder, f) for f in ("all.csv", "config.yml", "qmatrix.npz", "skill_wins.npz", "skill_fails.npz"))
+
+
+def get_new_data(dataset_name, data_folder="data"):
+    """the whole dataset as one frame - dataio.py:57-60 (fm.py:41)."""
+    return read_process(build_new_paths(dataset_name, data_folder)[1], sep=",")
+
+
+_AGENTS = ("users", "items", "skills", "attempts", "wins", "fails", "item_wins", "item_fails", "extra")   # dataio.py:67
+_MODEL_NAMES = (({"users", "items"}, False, "IRT: "), ({"users", "items"}, True, "MIRTb: "),
+                ({"skills", "attempts"}, False, "AFM: "), ({"skills", "wins", "fails"}, False, "PFA: "))
+
+
+def get_legend(experiment_args):
+    """Labels of an FM experiment from its switches (dataio.py:63-87): (short code, full legend, LaTeX legend, active blocks).
+    The short code takes one letter per active block - W / F for the item_wins / item_fails blocks - followed by the
+    dimension; the legends name the classical model the blocks amount to (IRT, MIRTb, AFM, PFA) where there is one."""
+    dim = experiment_args["d"]
+    active = [a for a in _AGENTS if experiment_args.get(a)]
+    letters = [("W" if "_w" in a else "F") if "_" in a else a[0] for a in active]
+    prefix = ""
+    for blocks, with_dim, name in _MODEL_NAMES:
+        if set(active) == blocks and (dim > 0) == with_dim and (with_dim or dim == 0):
+            prefix = name
+    latex = prefix + ", ".join(active)
+    return "".join(letters) + str(dim), latex + " d = {:d}".format(dim), latex, active
+
+
 def read_movielens(filename):
     """MovieLens ``user::item::rating::timestamp`` with 1-based ids (README.md:18-25) -> the same
     frame layout with 0-based ids."""
