@@ -225,6 +225,16 @@ int tfr_shard_route(tfr_model* m, const int32_t* d_user, const int32_t* d_item, 
  * happens inside the routing kernels and only the samples this rank owns leave the store. */
 int tfr_shard_route_ids(tfr_model* m, const int64_t* d_ids, int64_t batch_global, int32_t rank, int32_t world,
                         int64_t user_num_global, int64_t item_num_global, int32_t sample_cap, int32_t slot_cap, int32_t* d_req);
+/* pre-split batches (SURVEY 8e's other variant): every rank brings only ITS OWN batch rows d_ids[0..batch) of its store copy.
+ * tfr_shard_bucket_ids groups their 16-byte records {user, item, rate bits, position} by the owner of the user row into
+ * d_send = [world][pair_cap] records (batch order inside a group, unused slots have user = -1; overflow raises the error
+ * flag); after one equal-split all-to-all of that buffer tfr_shard_route_recs routes what arrived (n = world * pair_cap
+ * records, all owned by this rank) exactly as tfr_shard_route routes a global batch.  No rank ever looks at another rank's
+ * samples it does not own: the id draw and the ownership test cost B per rank, not world * B. */
+int tfr_shard_bucket_ids(tfr_model* m, const int64_t* d_ids, int64_t batch, int32_t world, int64_t user_num_global,
+                         int32_t pair_cap, void* d_send);
+int tfr_shard_route_recs(tfr_model* m, const void* d_recs, int64_t n, int32_t rank, int32_t world, int64_t user_num_global,
+                         int64_t item_num_global, int32_t sample_cap, int32_t slot_cap, int32_t* d_req);
 /* the routed batch, for the caller's bookkeeping and for tests: mine[sample_cap] global batch positions (-1 unused),
  * u_local[sample_cap], slot[sample_cap], counts = {local samples, distinct items, distinct items per owner [world]} */
 int tfr_shard_routed_devptrs(tfr_model* m, void** mine, void** u_local, void** slot, void** counts);

@@ -59,6 +59,36 @@ class OracleShard(object):
         sel = ids.long()
         return self.route(su[sel], si[sel], sr[sel], rank, world, U, I, sample_cap, slot_cap)
 
+    def bucket_ids(self, ids, world, U, pair_cap):
+        su, si, sr = self._store
+        sel = ids.long()
+        u, i, r = su[sel].numpy().astype(np.int64), si[sel].numpy().astype(np.int64), sr[sel].numpy().astype(np.float32)
+        per_u = -(-U // world)
+        send = np.full((world * pair_cap, 4), -1, np.int32)
+        owner = u // per_u
+        for w in range(world):
+            k = np.flatnonzero(owner == w)                 # batch order inside a group
+            if k.size > pair_cap:
+                raise IndexError("pair capacity exceeded")
+            send[w * pair_cap: w * pair_cap + k.size, 0] = u[k]
+            send[w * pair_cap: w * pair_cap + k.size, 1] = i[k]
+            send[w * pair_cap: w * pair_cap + k.size, 2] = r[k].view(np.int32)
+            send[w * pair_cap: w * pair_cap + k.size, 3] = k
+        return torch.from_numpy(send)
+
+    def route_recs(self, recv, rank, world, U, I, sample_cap, slot_cap):
+        rec = recv.numpy()
+        ok = np.flatnonzero(rec[:, 0] >= 0)
+        u = torch.from_numpy(rec[ok, 0].astype(np.int32)); i = torch.from_numpy(rec[ok, 1].astype(np.int32))
+        r = torch.from_numpy(rec[ok, 2].copy().view(np.float32))
+        req = self.route(u, i, r, rank, world, U, I, sample_cap, slot_cap)
+        # positions refer to the received buffer, as on the device
+        n = self._r["n"]
+        mine = self._r["mine"].numpy().copy()
+        mine[:n] = ok[mine[:n]]
+        self._r["mine"] = torch.from_numpy(mine)
+        return req
+
     def routed(self):
         return dict(mine=self._r["mine"], u_local=self._r["u_local"], slot=self._r["slot_t"], counts=self._r["counts"])
 

@@ -36,7 +36,31 @@ def _worker(rank, world, port, kw, U, I, D, B, steps):
         comm = sharded.Comm()
         m = sharded.ShardedSvd(U, I, D, comm, lambda ur, ir, d: sharded.HipShard(ur, ir, d, 0, **kw), device=dev)
         m.set_tables_from_global(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        # a rating store every rank holds a copy of: the last step is a pre-split one (each rank brings its own rows of it)
+        Ns = 2 * B + 3
+        su, si = dup_heavy_ids(rs, U, Ns), dup_heavy_ids(rs, I, Ns)
+        sr = (rs.rand(Ns) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, Ns).astype(np.float32)
+        keep = [torch.from_numpy(x).to(dev) for x in (su, si, sr)]
+        m.backend.set_store(*keep)
+        rs_own = np.random.RandomState(500 + rank)
         for s in range(steps):
+            if s == steps - 1 and steps > 1:
+                my = rs_own.randint(0, Ns, max(1, B // world))
+                allids = [None] * world
+                dist.all_gather_object(allids, my)
+                union = np.concatenate(allids)
+                u, i, r = su[union], si[union], sr[union]
+                logits, mine, scal = m.train_step_local_ids(torch.from_numpy(my).to(dev))
+                torch.cuda.synchronize()
+                wl, wloss, wreg = ref.train_step(u, i, r)
+                tol = RTOL * (s + 1)
+                sc = scal.cpu().numpy()
+                assert abs(sc[0] - wloss) <= tol * abs(wloss) and abs(sc[1] - wreg) <= tol * abs(wreg)
+                n = int(m.backend.routed()["counts"][0].item())
+                counts = [None] * world
+                dist.all_gather_object(counts, n)
+                assert sum(counts) == union.size
+                continue
             u, i = dup_heavy_ids(rs, U, B), dup_heavy_ids(rs, I, B)
             r = (rs.rand(B) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, B).astype(np.float32)
             logits, mine, scal = m.train_step(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev),
@@ -117,6 +141,30 @@ def test_device_routing_is_bit_exact_against_numpy():
             g = hip.routed()
             for k in ("counts", "mine", "u_local", "slot"):
                 assert np.array_equal(g[k].cpu().numpy(), w[k].numpy()), ("ids", k, U, I, world, rank)
+            # pre-split batches: every sender's own rows grouped by owner (tfr_shard_bucket_ids), then the routing of what this
+            # rank would receive from them (tfr_shard_route_recs) - both bit for bit against NumPy
+            b_loc = max(1, Bg // world)
+            pair_cap = sh.pair_capacity(b_loc)
+            ora.set_store(torch.from_numpy(su), torch.from_numpy(si), torch.from_numpy(sr))
+            recv_parts = []
+            for sender in range(world):
+                ids_s = np.random.RandomState(sender * 7 + U).randint(0, Ns, b_loc).astype(np.int64)
+                want_send = ora.bucket_ids(torch.from_numpy(ids_s), world, U, pair_cap)
+                if sender in (0, world - 1):               # the device kernels for two of the senders
+                    got_send = hip.bucket_ids(torch.from_numpy(ids_s).to(dev), world, U, pair_cap)
+                    hip.sync()
+                    assert np.array_equal(got_send.cpu().numpy(), want_send.numpy()), ("bucket", U, I, world, sender)
+                recv_parts.append(want_send.numpy()[rank * pair_cap:(rank + 1) * pair_cap])
+            recv = np.ascontiguousarray(np.concatenate(recv_parts))
+            sc2, sl2 = sh.capacities(b_loc * world)
+            sc2 = min(sc2, world * pair_cap)
+            want_req = ora.route_recs(torch.from_numpy(recv), rank, world, U, I, sc2, sl2)
+            got_req = hip.route_recs(torch.from_numpy(recv).to(dev), rank, world, U, I, sc2, sl2)
+            hip.sync()
+            assert np.array_equal(got_req.cpu().numpy(), want_req.numpy()), ("recs", U, I, world, rank)
+            g, w = hip.routed(), ora.routed()
+            for k in ("counts", "mine", "u_local", "slot"):
+                assert np.array_equal(g[k].cpu().numpy(), w[k].numpy()), ("recs", k, U, I, world, rank)
             hip.model.close()
 
 

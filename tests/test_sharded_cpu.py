@@ -41,7 +41,33 @@ def _worker(rank, world, port, kw, U, I, D, B, steps):
         su, si = dup_heavy_ids(rs, U, Ns), dup_heavy_ids(rs, I, Ns)
         sr = (rs.rand(Ns) < 0.5).astype(np.float32) if kw.get("loss") == "nll" else rs.randint(1, 6, Ns).astype(np.float32)
         m.backend.set_store(torch.from_numpy(su), torch.from_numpy(si), torch.from_numpy(sr))
+        rs_own = np.random.RandomState(1000 + rank)      # pre-split batches: every rank's own id stream
         for s in range(steps):
+            if s % 3 == 2:
+                # every rank brings its own B // world store rows; the records travel to the owners of their user rows
+                b_loc = max(1, B // world)
+                my = rs_own.randint(0, Ns, b_loc)
+                allids = [None] * world
+                dist.all_gather_object(allids, my)
+                union = np.concatenate(allids)
+                u, i, r = su[union], si[union], sr[union]
+                logits, mine, scal = m.train_step_local_ids(torch.from_numpy(my))
+                want_logits, want_loss, want_reg = ref.train_step(u, i, r)
+                n = int(m.backend.routed()["counts"][0])
+                counts = [None] * world
+                dist.all_gather_object(counts, n)
+                assert sum(counts) == union.size                      # every sample reached exactly one owner
+                assert abs(scal[0].item() - want_loss) <= 1e-10 * max(1.0, abs(want_loss))
+                assert abs(scal[1].item() - want_reg) <= 1e-10 * max(1.0, abs(want_reg))
+                # the logits of the samples this rank now owns: position k of the received buffer = sender k // pair_cap
+                pair_cap = m.pair_capacity(b_loc)
+                pos = mine.numpy()[:n]
+                src, within = pos // pair_cap, pos % pair_cap
+                for q in range(n):
+                    sent = np.flatnonzero(su[allids[src[q]]] // m.per_u == rank)      # what sender src[q] had for this owner, in batch order
+                    k_union = sum(len(a) for a in allids[:src[q]]) + sent[within[q]]
+                    assert abs(logits.numpy()[q] - want_logits[k_union]) <= 1e-12 * max(1.0, abs(want_logits[k_union]))
+                continue
             if s % 2:
                 ids = rs.randint(0, Ns, B)
                 u, i, r = su[ids], si[ids], sr[ids]

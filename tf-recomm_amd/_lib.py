@@ -93,6 +93,8 @@ SIGNATURES = {
     "tfr_shard_row_stride": (C.c_int32, [_p]),
     "tfr_shard_route": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _p]),
     "tfr_shard_route_ids": (C.c_int, [_p, _p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _p]),
+    "tfr_shard_bucket_ids": (C.c_int, [_p, _p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _p]),
+    "tfr_shard_route_recs": (C.c_int, [_p, _p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _p]),
     "tfr_shard_routed_devptrs": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "tfr_shard_gather": (C.c_int, [_p, _p, C.c_int64, _p]),
     "tfr_shard_forward_reduce": (C.c_int, [_p, _p, _p, _p, _p]),

@@ -2138,9 +2138,9 @@ int32_t tfr_shard_row_stride(tfr_model* m) { return m ? shard_stride(m) : 0; }
 
 static int shard_route_core(tfr_model* m, const int32_t* d_user, const int32_t* d_item, const float* d_rate, const int64_t* d_ids,
                             int64_t Bg, int32_t rank, int32_t world, int64_t U_global, int64_t I_global, int32_t sample_cap,
-                            int32_t slot_cap, int32_t* d_req) {
+                            int32_t slot_cap, int32_t* d_req, const int4* d_recs = nullptr) {
     if (Bg < 0 || world < 1 || rank < 0 || rank >= world || sample_cap < 1 || slot_cap < 1 || !d_req || U_global < 1 || I_global < 1 ||
-        I_global >= 0x7fffffffLL || U_global >= 0x7fffffffLL || (Bg > 0 && !d_ids && (!d_user || !d_item || !d_rate)))
+        I_global >= 0x7fffffffLL || U_global >= 0x7fffffffLL || (Bg > 0 && !d_ids && !d_recs && (!d_user || !d_item || !d_rate)))
         return fail(TFR_ERR_ARG, "shard_route: bad arguments");
     if ((int64_t)world * slot_cap >= 0x7fffffffLL) return fail(TFR_ERR_ARG, "shard_route: world * slot_cap too large");
     int rc;
@@ -2161,6 +2161,7 @@ static int shard_route_core(tfr_model* m, const int32_t* d_user, const int32_t* 
     memset(&a, 0, sizeof(a));
     a.u = d_user; a.it = d_item; a.r = d_rate; a.Bg = Bg; a.U = U_global; a.I = I_global;
     if (d_ids) { a.ids = d_ids; a.store = m->store; a.N = m->N; }
+    a.recs = d_recs;
     a.per_u = (U_global + world - 1) / world; a.per_i = (I_global + world - 1) / world; a.u_lo = a.per_u * rank;
     a.rank = rank; a.world = world; a.Bcap = sample_cap; a.cap = slot_cap;
     a.u_pad = (int32_t)m->U; a.i_pad = (int32_t)I_global;
@@ -2195,6 +2196,35 @@ int tfr_shard_route_ids(tfr_model* m, const int64_t* d_ids, int64_t Bg, int32_t 
     if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples / tfr_set_triples_dev first (global row ids)");
     if (Bg > 0 && !d_ids) return fail(TFR_ERR_ARG, "shard_route_ids: null ids");
     return shard_route_core(m, nullptr, nullptr, nullptr, d_ids, Bg, rank, world, U_global, I_global, sample_cap, slot_cap, d_req);
+}
+
+int tfr_shard_bucket_ids(tfr_model* m, const int64_t* d_ids, int64_t B, int32_t world, int64_t U_global, int32_t pair_cap,
+                         void* d_send) {
+    MODEL_ENTER(m);
+    if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples / tfr_set_triples_dev first (global row ids)");
+    if (B < 0 || world < 1 || world > 4096 || U_global < 1 || pair_cap < 1 || !d_send || (B > 0 && !d_ids))
+        return fail(TFR_ERR_ARG, "shard_bucket_ids: bad arguments");
+    int rc;
+    const int64_t nblocks = (B + 1023) / 1024 > 0 ? (B + 1023) / 1024 : 1;
+    const int64_t need = nblocks * world > B ? nblocks * world : (B > 0 ? B : 1);
+    if ((rc = ensure_capacity(m, need))) return rc;
+    hipStream_t s = m->stream;
+    HIPCHK(hipMemsetAsync(d_send, 0xff, (size_t)world * pair_cap * sizeof(int4), s));      // every slot unused (u = -1)
+    BucketArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ids = d_ids; a.store = m->store; a.N = m->N; a.B = B; a.U = U_global; a.per_u = (U_global + world - 1) / world;
+    a.world = world; a.cap = pair_cap; a.send = reinterpret_cast<int4*>(d_send); a.blk = m->lrank_u; a.err = m->d_err;
+    launch_bucket(a, s);
+    HIPCHK(hipGetLastError());
+    return TFR_OK;
+}
+
+int tfr_shard_route_recs(tfr_model* m, const void* d_recs, int64_t n, int32_t rank, int32_t world, int64_t U_global,
+                         int64_t I_global, int32_t sample_cap, int32_t slot_cap, int32_t* d_req) {
+    MODEL_ENTER(m);
+    if (n > 0 && !d_recs) return fail(TFR_ERR_ARG, "shard_route_recs: null records");
+    return shard_route_core(m, nullptr, nullptr, nullptr, nullptr, n, rank, world, U_global, I_global, sample_cap, slot_cap, d_req,
+                            reinterpret_cast<const int4*>(d_recs));
 }
 
 int tfr_shard_routed_devptrs(tfr_model* m, void** mine, void** u_local, void** slot, void** counts) {

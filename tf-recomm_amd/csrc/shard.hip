@@ -34,7 +34,11 @@ __device__ __forceinline__ int block_rank_1024(bool flag, int* total) {
 // sample k of the global batch: columns u / it / r, or (ids != NULL) row ids[k] of the rank's copy of the rating store -
 // the fused ShuffleIterator gather, as in the single-GPU step: only the samples a rank owns ever leave the store as columns
 __device__ __forceinline__ bool route_sample(const RouteArgs& a, int64_t k, int32_t* u, int32_t* it, float* r, bool* bad, bool* bad_id) {
-    if (a.ids) {
+    if (a.recs) {
+        const int4 rec = a.recs[k];
+        if (rec.x < 0) return false;                     // unused slot of the exchange buffer
+        *u = rec.x; *it = rec.y; *r = __int_as_float(rec.z);
+    } else if (a.ids) {
         int64_t id = a.ids[k];
         if ((uint64_t)id >= (uint64_t)a.N) { *bad_id = true; return false; }
         const int4 rec = a.store[id];
@@ -48,7 +52,68 @@ __device__ __forceinline__ bool route_sample(const RouteArgs& a, int64_t k, int3
 __device__ __forceinline__ bool route_mine(const RouteArgs& a, int64_t k, bool* bad, bool* bad_id, int32_t* u, int32_t* it, float* r) {
     if (k >= a.Bg) return false;
     if (!route_sample(a, k, u, it, r, bad, bad_id)) return false;
+    if (a.recs && (int64_t)*u / a.per_u != a.rank) { *bad = true; return false; }      // a peer sent a sample this rank does not own
     return (int64_t)*u / a.per_u == a.rank;
+}
+
+// ---- pre-split batches: bucket this rank's own samples by the owner of their user row --------------------------------------
+__device__ __forceinline__ int bucket_owner(const BucketArgs& a, int64_t k, int4* rec, bool* bad, bool* bad_id) {
+    if (k >= a.B) return -1;
+    int64_t id = a.ids[k];
+    if ((uint64_t)id >= (uint64_t)a.N) { *bad_id = true; return -1; }
+    *rec = a.store[id];
+    if ((uint64_t)(int64_t)rec->x >= (uint64_t)a.U) { *bad = true; return -1; }
+    return (int)((int64_t)rec->x / a.per_u);
+}
+
+// per 1024-sample block and owner: how many samples (integer LDS counters: order does not matter)
+__global__ __launch_bounds__(1024) void k_bucket_count(BucketArgs a) {
+    extern __shared__ int32_t ocnt[];                    // [world]
+    for (int w = threadIdx.x; w < a.world; w += 1024) ocnt[w] = 0;
+    __syncthreads();
+    bool bad = false, bad_id = false;
+    int4 rec;
+    const int w = bucket_owner(a, (int64_t)blockIdx.x * 1024 + threadIdx.x, &rec, &bad, &bad_id);
+    if (w >= 0) atomicAdd(&ocnt[w], 1);
+    __syncthreads();
+    for (int q = threadIdx.x; q < a.world; q += 1024) a.blk[(size_t)blockIdx.x * a.world + q] = ocnt[q];
+    if (bad) atomicOr(a.err, 1);
+    if (bad_id) atomicOr(a.err, 2);
+}
+
+// per owner: exclusive scan of its counts over the blocks (one thread per owner; a few hundred blocks)
+__global__ __launch_bounds__(256) void k_bucket_scan(int32_t* blk, int nblocks, int world, int32_t cap, int32_t* err) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= world) return;
+    int run = 0;
+    for (int b = 0; b < nblocks; ++b) { const int c = blk[(size_t)b * world + w]; blk[(size_t)b * world + w] = run; run += c; }
+    if (run > cap) atomicOr(err, 4);
+}
+
+// the records, in batch order inside every owner's group
+__global__ __launch_bounds__(1024) void k_bucket_scatter(BucketArgs a) {
+    bool bad = false, bad_id = false;
+    int4 rec = make_int4(-1, -1, 0, -1);
+    const int64_t k = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int w = bucket_owner(a, k, &rec, &bad, &bad_id);
+    // stable rank among the block's samples of the same owner: one ordered ballot count per owner present in the world
+    int myrank = 0;
+    for (int q = 0; q < a.world; ++q) {                  // block-uniform loop; two barriers per owner
+        int tot;
+        const int r = block_rank_1024(w == q, &tot);
+        if (w == q) myrank = r;
+    }
+    if (w >= 0) {
+        const int dst = a.blk[(size_t)blockIdx.x * a.world + w] + myrank;
+        if (dst < a.cap) a.send[(size_t)w * a.cap + dst] = make_int4(rec.x, rec.y, rec.z, (int32_t)k);
+    }
+}
+
+void launch_bucket(const BucketArgs& a, hipStream_t s) {
+    const int nb = (int)((a.B + 1023) / 1024 > 0 ? (a.B + 1023) / 1024 : 1);
+    hipLaunchKernelGGL(k_bucket_count, dim3(nb), dim3(1024), (size_t)a.world * 4, s, a);
+    hipLaunchKernelGGL(k_bucket_scan, dim3((a.world + 255) / 256), dim3(256), 0, s, a.blk, nb, a.world, a.cap, a.err);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(nb), dim3(1024), 0, s, a);
 }
 
 // phase 1a: per 1024-sample block, how many samples are this rank's (and the global range check)

@@ -231,6 +231,8 @@ void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hip
 struct RouteArgs {
     const int32_t* u; const int32_t* it; const float* r;     // the GLOBAL batch [Bg], identical on every rank
     const int64_t* ids; const int4* store; int64_t N;        // or (ids != NULL): rows ids[0..Bg) of the rank's copy of the rating store
+    const int4* recs;                                        // or (recs != NULL): records {u, i, r bits, origin} received from the peers
+                                                             // (pre-split batches, launch_bucket); u < 0 = unused slot
     int64_t Bg, U, I;                                        // global row counts (range check)
     int64_t per_u, per_i, u_lo;                              // block partition: owner = id / per
     int32_t rank, world, Bcap, cap;                          // capacities: local samples, request slots per owner
@@ -243,6 +245,16 @@ struct RouteArgs {
     int32_t* err;                                            // |= 1 id out of range, |= 4 capacity exceeded
 };
 void launch_route_compact(const RouteArgs& a, hipStream_t s);    // mine / u_local / it_glob / r_loc, counts[0]
+// pre-split batches (SURVEY 8e's other variant): this rank's own B samples, as rows ids[] of its store copy, go into a
+// fixed-capacity send buffer [world][cap] of 16-byte records grouped by the owner of their user row (stable: batch order
+// inside a group); unused slots keep u = -1 (the caller presets the buffer to 0xff)
+struct BucketArgs {
+    const int64_t* ids; const int4* store; int64_t N, B, U, per_u;
+    int32_t world, cap;
+    int4* send; int32_t* blk;                                // blk: [nblocks * world] counts, then offsets (scratch)
+    int32_t* err;                                            // |= 2 id out of range, |= 1 user id out of range, |= 4 capacity exceeded
+};
+void launch_bucket(const BucketArgs& a, hipStream_t s);
 void launch_route_slots(const RouteArgs& a, hipStream_t s);      // after the sort: slot, req, counts[1..]
 struct GatherPackedArgs {
     const int32_t* ids; const float* table; const float* bias; float* out; int32_t* err;

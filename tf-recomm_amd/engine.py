@@ -299,6 +299,13 @@ class SvdModel:
         L.check(self._lib.tfr_shard_route_ids(self._h, d_ids, batch_global, rank, world, user_num_global, item_num_global,
                                               sample_cap, slot_cap, d_req))
 
+    def shard_bucket_ids(self, d_ids, batch, world, user_num_global, pair_cap, d_send):
+        L.check(self._lib.tfr_shard_bucket_ids(self._h, d_ids, batch, world, user_num_global, pair_cap, d_send))
+
+    def shard_route_recs(self, d_recs, n, rank, world, user_num_global, item_num_global, sample_cap, slot_cap, d_req):
+        L.check(self._lib.tfr_shard_route_recs(self._h, d_recs, n, rank, world, user_num_global, item_num_global,
+                                               sample_cap, slot_cap, d_req))
+
     def shard_routed_devptrs(self):
         ps = [L._p() for _ in range(4)]
         L.check(self._lib.tfr_shard_routed_devptrs(self._h, *[C.byref(p) for p in ps]))

@@ -161,6 +161,23 @@ class HipShard(object):
         self._routed = (sample_cap, world)
         return req
 
+    def bucket_ids(self, ids, world, U, pair_cap):
+        """this rank's own batch rows -> [world * pair_cap, 4] int32 records grouped by the owner of the user row"""
+        send = self._get("send", (world * pair_cap, 4), torch.int32)
+        self._sync_in()
+        self.model.shard_bucket_ids(ids.data_ptr(), ids.numel(), world, U, pair_cap, send.data_ptr())
+        self._sync_out()
+        return send
+
+    def route_recs(self, recv, rank, world, U, I, sample_cap, slot_cap):
+        """`route` on the records received from the peers (all owned by this rank; user = -1 marks an unused slot)"""
+        req = self._get("req", (world * slot_cap,), torch.int32)
+        self._sync_in()
+        self.model.shard_route_recs(recv.data_ptr(), recv.shape[0], rank, world, U, I, sample_cap, slot_cap, req.data_ptr())
+        self._sync_out()
+        self._routed = (sample_cap, world)
+        return req
+
     def routed(self):
         """views of the routed batch (test / bookkeeping): mine, u_local, slot [sample_cap]; counts [2 + world]"""
         cap, world = self._routed
@@ -255,6 +272,14 @@ class ShardedSvd(object):
         sample_cap = min(Bg, int(self.slack * Bg / W) + 4096)
         return sample_cap, max(1, min(self.per_i, sample_cap, int(self.slack * Bg / (W * W)) + 1024))
 
+    def pair_capacity(self, batch_local):
+        """records one rank may send to one owner per step (pre-split batches): the whole batch while that is small (an exact
+        bound), else ``slack`` x the expected share at uniform user ids"""
+        B, W = int(batch_local), self.world
+        if B * W <= 65536:
+            return max(1, B)
+        return min(B, int(self.slack * B / W) + 1024)
+
     def _phase(self, name):
         if self.timers is None:
             return None
@@ -287,6 +312,26 @@ class ShardedSvd(object):
         sample_cap, slot_cap = self.capacities(ids.numel())
         t = self._phase("route")
         req = self.backend.route_ids(ids, self.rank, self.world, self.U, self.I, sample_cap, slot_cap)
+        self._end(t)
+        return self._exchange_and_update(req)
+
+    def train_step_local_ids(self, ids):
+        """Pre-split batches (SURVEY 8e's other variant): ``ids`` are THIS rank's own B rows of the rating store (int64 tensor;
+        every rank brings a different batch - e.g. its own id stream).  The records are grouped by the owner of their user row,
+        one more equal-split all-to-all (16 bytes per sample) takes them there, and the step goes on as for a global batch of
+        ``world * pair_capacity`` slots.  No rank draws, reads or tests a sample of another rank's batch that it does not own."""
+        c, be = self.comm, self.backend
+        pair_cap = self.pair_capacity(ids.numel())
+        sample_cap, slot_cap = self.capacities(ids.numel() * self.world)
+        sample_cap = min(sample_cap, self.world * pair_cap)
+        t = self._phase("bucket")
+        send = be.bucket_ids(ids, self.world, self.U, pair_cap)
+        self._end(t)
+        t = self._phase("all_to_all samples")
+        recv = c.all_to_all(send)
+        self._end(t)
+        t = self._phase("route")
+        req = be.route_recs(recv, self.rank, self.world, self.U, self.I, sample_cap, slot_cap)
         self._end(t)
         return self._exchange_and_update(req)
 
@@ -358,13 +403,30 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
     su = torch.randint(0, U, (N,), dtype=torch.int32, device=dev, generator=g)
     si = torch.randint(0, I, (N,), dtype=torch.int32, device=dev, generator=g)
     sr = torch.randint(1, 6, (N,), device=dev, generator=g).to(torch.float32)
-    np.random.seed(13575)
-    ids = torch.from_numpy(np.random.randint(0, N, (W + K, Bg))).to(dev)
+    m.backend.set_store(su, si, sr)                      # every rank's own copy of the store; the kernels gather from it
+    # pre-split batches with the id draw inside the loop, as at N=1: rank r draws ITS B rows per step with
+    # np.random.seed(13575 + r); randint(0, N, (B,)) on the device generator (side stream, CH steps' ids per draw, two draws
+    # ahead, three buffers); the records then travel to the owners of their user rows (train_step_local_ids).  A global stream
+    # that every rank routes (train_step_ids) would make each rank generate and test world * B ids per step.
+    np.random.seed(13575 + rank)
+    be_model = m.backend.model
+    be_model.rng_from_numpy()
+    CH = 4
+    ids_buf = torch.empty((3, CH * B), dtype=torch.int64, device=dev)
+    issued, done = [0], [0]
 
-    m.backend.set_store(su, si, sr)                      # every rank's own copy of the store; the routing kernels gather from it
+    def issue():
+        be_model.draw_ids_dev(N, CH * B, ids_buf[issued[0] % 3].data_ptr())
+        issued[0] += 1
+    issue(); issue()
 
-    def step(s):
-        return m.train_step_ids(ids[s])
+    def step(_s):
+        s = done[0]
+        if s % CH == 0:
+            be_model.join_draws()
+            issue()
+        done[0] += 1
+        return m.train_step_local_ids(ids_buf[(s // CH) % 3][(s % CH) * B:(s % CH + 1) * B])
     # untimed set-up before the W warm-up steps: one-off costs of a process's first collectives (a single 40 ms stall between
     # steps 10 and 20 at world 1: 1.33 ms per step in the steady state, 2.0 ms when it fell into a 40-step timed region)
     for s in range(SETUP_STEPS if W < SETUP_STEPS else 0):
@@ -395,7 +457,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
     for name, e0, e1 in m.timers:
         phases[name] = phases.get(name, 0.0) + e0.elapsed_time(e1) * 1e3 / min(K, 10)
     m.timers = None
-    wire = m.wire_bytes_per_step(Bg)
+    wire = m.wire_bytes_per_step(Bg) + (world - 1) * m.pair_capacity(B) * 16      # + the sample records
     step_s = elapsed / K
     exch_us = sum(v for k, v in phases.items() if k.startswith("all_to_all"))
     xgmi = wire / step_s / 1e9
@@ -405,8 +467,9 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                 config=dict(workload="%s: %s" % (workload_key, wl["name"]), untimed_setup_steps=SETUP_STEPS if W < SETUP_STEPS else 0, users=U, items=I, dim=D, global_batch=Bg, per_gpu_batch=B,
                             optimizer="adam", adam_mode=wl["adam_mode"], sample_cap=sample_cap, slot_cap=slot_cap,
-                            parallelism="row-sharded tables x%d: device-side routing, 3 equal-split all-to-alls (request slots, "
-                                        "packed rows, packed gradient rows) + one 16-byte all-reduce per step over RCCL, no host sync" % world),
+                            parallelism="row-sharded tables x%d, pre-split batches (rank r draws its own B rows per step on the device, seed 13575 + r): "
+                                        "device-side routing, 4 equal-split all-to-alls (sample records, request slots, packed rows, packed "
+                                        "gradient rows) + one 16-byte all-reduce per step over RCCL, no host sync" % world),
                 roofline=dict(kernel="all_to_all (%s)" % ("gloo rehearsal: staged through host memory, times meaningless" if comm.stage else "RCCL over xGMI"), bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
                               frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire,
                               exchange_us_per_step=exch_us, phases_us=phases,
