@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TFR_ABI_VERSION 1
+#define TFR_ABI_VERSION 3
 
 typedef struct tfr_model tfr_model;
 
@@ -348,6 +348,9 @@ int tfr_sync(tfr_model* m);            /* drains the stream; reports deferred TF
 const char* tfr_last_error(void);
 int tfr_version(void);
 int tfr_device_count(void);
+/* Measurement yardstick (bench.py): GB/s (read + write bytes) of the library's own float4 grid-stride copy kernel over
+ * `bytes` of device memory, best and mean of `reps` launches timed by HIP events.  Replaces no reference call. */
+int tfr_device_copy_rate(int32_t device, int64_t bytes, int32_t reps, double* best_gbs, double* mean_gbs);
 
 #ifdef __cplusplus
 }

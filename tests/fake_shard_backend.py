@@ -95,7 +95,7 @@ class OracleShard(object):
     @property
     def stride(self):
         D = self.o.D
-        return D + 4 if D % 4 == 0 else D + 1
+        return D + 4 if D % 4 == 0 else D + 2
 
     def gather(self, req_recv):
         ids = req_recv.numpy().astype(np.int64)

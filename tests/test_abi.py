@@ -31,7 +31,7 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_version_and_default_opts():
     lib = L.load()
-    assert lib.tfr_version() == 1
+    assert lib.tfr_version() == L.ABI_VERSION == 3
     o = L.TfrOpts()
     lib.tfr_default_opts(C.byref(o))
     assert (o.loss, o.item_abs, o.reg_bias, o.optimizer, o.adam_mode) == (0, 0, 0, 0, 0)

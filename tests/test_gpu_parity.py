@@ -448,6 +448,8 @@ def _sweep_cases():
     cases.append((106, 9000, 16384, 256, 12289, "sgd", "tf1", "nll", True, False))
     # the headline configuration itself (BASELINE configs[1]): k_tile_step<16,4,2> + k_dense_tiles<16,4,false,10>
     cases.append((107, 6040, 3952, 64, 10000, "adam", "tf1", "mse", False, False))
+    # BASELINE configs[0] at its exact shape (the reference's CPU-runnable case): VEC=1 rows of 15 floats, one tile
+    cases.append((108, 6040, 3952, 15, 1000, "adam", "tf1", "mse", False, False))
     return cases
 
 

@@ -316,13 +316,18 @@ def test_discrete_driver_logs_the_forks_epoch_line():
     train, val = mk(slice(0, 5000)), mk(slice(5000, n))
     lines = []
     np.random.seed(13575)
-    rows = svd_train_val.svd(train, val, user_num=U, item_num=I, dim=8, batch_size=500, epoch_max=4, learning_rate=0.05,
+    # learning rate: the fork's SGD runs on the SUMMED loss (ops.py:140), so the effective step is lr x 500.  The float64
+    # oracle on the same data (3 initialisations) diverges at 0.05 (test NLL 0.85 -> 2-4) and falls monotonically at 0.01
+    # (0.85 -> 0.71 over six epochs): 0.01 is where "the driver improves the NLL" is a property of the arithmetic.
+    rows = svd_train_val.svd(train, val, user_num=U, item_num=I, dim=8, batch_size=500, epoch_max=6, learning_rate=0.01,
                              reg=0.001, discrete=True, log=lines.append)
     ep = [l for l in lines if "TRAIN(" in l]
-    assert len(ep) == len(rows) == 4
+    assert len(ep) == len(rows) == 6
     m = re.search(r"TRAIN\(size=500/5000, macc=([\d.]+), mauc=([\d.]+), mnll=([\d.]+)\) TEST\(size=1000, macc=([\d.]+), auc=([\d.]+), mnll=([\d.]+)\)", ep[-1])
     assert m, ep[-1]
     tr_acc, tr_auc, tr_nll, te_acc, te_auc, te_nll = map(float, m.groups())
     assert 0.5 < tr_auc <= 1.0 and 0.5 < te_auc <= 1.0 and 0 < tr_nll < 10 and 0 < te_nll < 10
-    first = re.search(r"TEST\(size=1000, macc=([\d.]+), auc=([\d.]+), mnll=([\d.]+)\)", ep[0])
-    assert te_auc > float(first.group(2))                       # it learns to rank (sum-loss SGD at this rate does not calibrate)
+    tests = [re.search(r"TEST\(size=1000, macc=([\d.]+), auc=([\d.]+), mnll=([\d.]+)\)", l) for l in ep]
+    nlls, aucs = [float(t.group(3)) for t in tests], [float(t.group(2)) for t in tests]
+    assert aucs[-1] > aucs[0]                                    # it learns to rank
+    assert nlls[-1] < nlls[0] - 0.02 and all(b < a + 1e-3 for a, b in zip(nlls, nlls[1:])), nlls   # and the test NLL falls, epoch by epoch

@@ -189,6 +189,60 @@ def test_capacity_overflow_voids_the_step_loudly():
     hip.model.close()
 
 
+def _one_rank_overflows(rank, world, port, D):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfrecomm_amd import sharded, _lib as L
+        import tfrecomm_amd as T
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        U, I, B = 2000, 300, 40000
+        rs = np.random.RandomState(5)
+        t = rand_tables(rs, U, I, D)
+        kw = dict(optimizer="adam", adam_mode="lazy")
+        comm = sharded.Comm()
+        m = sharded.ShardedSvd(U, I, D, comm, lambda ur, ir, d: sharded.HipShard(ur, ir, d, 0, **kw), device=dev)
+        m.set_tables_from_global(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+        # store rows [0, B): every user in rank 1's block (a hot user block); rows [B, 2B): uniform users
+        su = np.concatenate([rs.randint(U // 2, U, B), rs.randint(0, U, B)]).astype(np.int32)
+        si = rs.randint(0, I, 2 * B).astype(np.int32)
+        sr = rs.randint(1, 6, 2 * B).astype(np.float32)
+        keep = [torch.from_numpy(x).to(dev) for x in (su, si, sr)]
+        m.backend.set_store(*keep)
+        assert m.pair_capacity(B) < B                            # slack-sized: rank 0's 40000 records for rank 1 do not fit
+        before = {k: np.array(v) for k, v in m.local_tables().items()}
+        # rank 0 brings only hot-block rows -> its bucket for owner 1 overflows; rank 1's own batch is harmless
+        my = np.arange(B, dtype=np.int64) if rank == 0 else B + np.arange(B, dtype=np.int64)
+        ids = torch.from_numpy(my).to(dev)
+        m.train_step_local_ids(ids)
+        m.train_step_local_ids(ids)                              # the flag is sticky until a sync: the next step is void as well
+        with pytest.raises(T.TfrError) as e:
+            m.backend.sync()
+        assert e.value.code == L.ERR_OOB
+        assert ("capacit" in str(e.value)) if rank == 0 else ("another rank" in str(e.value)), str(e.value)
+        after = m.local_tables()
+        for k in before:                                         # void on EVERY rank: no table moved anywhere
+            assert np.array_equal(before[k], np.asarray(after[k])), "rank %d table %d moved in a void step" % (rank, k)
+        # and the ranks are still in step with each other: a batch that fits goes through on both
+        ok_ids = torch.from_numpy(B + rs.randint(0, B, B).astype(np.int64)).to(dev)
+        m.train_step_local_ids(ok_ids)
+        m.backend.sync()
+        moved = m.local_tables()
+        assert not np.array_equal(before[L.P], np.asarray(moved[L.P]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("D", [64, 6])
+def test_overflow_on_one_rank_voids_the_step_on_every_rank(D):
+    """a capacity overflow on ONE rank (a hot user block) must not let the peers apply that rank's stale gradient
+    rows: the error flag rides with the packed rows of the row exchange, every rank skips the same step and raises at its
+    next sync.  D=6 takes the unvectorised row layout (stride D + 2)."""
+    mp.spawn(_one_rank_overflows, args=(2, _free_port(), D), nprocs=2, join=True)
+
+
 # ------------------------------------------------------------------ data parallel (replicated tables)
 def _dp_worker(rank, world, port, kw, U, I, D, B, steps):
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -100,3 +100,21 @@ def test_csv_loaders_match_the_reference_readers_frames(golden):
             assert np.array_equal(df[c].to_numpy(), g["%s/%s" % (name, c)], equal_nan=True), (name, c)
     cfg = dataio.get_config(os.path.join(root, "data", "tiny", "config.yml"))
     assert cfg == {"USER_NUM": 40, "ITEM_NUM": 30, "NB_CLASSES": 2, "BATCH_SIZE": 8}
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the form the driver uses at N=1) must start two
+    ranks itself, before anything touches a GPU.  In this GPU-less container each child then stops at "no HIP device";
+    the parent relays that and returns their code instead of raising SystemExit("launch with torch.distributed.run")."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = env["ROCR_VISIBLE_DEVICES"] = ""         # also on a GPU box: this test is about the launcher
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = p.stderr.decode()
+    assert "started 2 ranks" in err, err
+    assert "rank 0/2 needs an MI355X" in err and "rank 1/2 needs an MI355X" in err, err
+    assert p.returncode != 0 and p.stdout.decode().strip() == ""

@@ -7,10 +7,10 @@ kernels behind the C-ABI of include/tfrecomm.h.  Import as ``import tfrecomm_amd
 """
 from . import _lib
 from ._lib import TfrError, OutOfRangeError
-from .engine import SvdModel
+from .engine import SvdModel, device_copy_rate
 from . import dataio, graph, ops, config, cats, adaptive_test
 from .fm import FmModel
 from .als import MangakiALS3
 
-__all__ = ["SvdModel", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config", "cats", "adaptive_test",
+__all__ = ["SvdModel", "device_copy_rate", "TfrError", "OutOfRangeError", "_lib", "dataio", "graph", "ops", "config", "cats", "adaptive_test",
            "FmModel", "MangakiALS3"]

@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtfrecomm_hip.so")
 
+ABI_VERSION = 3       # include/tfrecomm.h TFR_ABI_VERSION this binding was written against (checked at load)
 OK, ERR_ARG, ERR_OOB, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 MU, BU, BI, P, Q = 0, 1, 2, 3, 4
 SLOT_M, SLOT_V = 8, 16
@@ -134,6 +135,7 @@ SIGNATURES = {
     "tfr_last_error": (C.c_char_p, []),
     "tfr_version": (C.c_int, []),
     "tfr_device_count": (C.c_int, []),
+    "tfr_device_copy_rate": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _f64p, _f64p]),
 }
 
 _lib = None
@@ -148,6 +150,12 @@ def load():
                 "%s not found: the HIP extension is not built (run __graft_entry__.build()). "
                 "There is no CPU fallback." % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
+        lib.tfr_version.restype = C.c_int
+        lib.tfr_version.argtypes = []
+        got = lib.tfr_version()
+        if got != ABI_VERSION:      # a stale .so under a newer binding (or the reverse) would be called with the wrong argument layout
+            raise ImportError("%s reports ABI version %d, this binding needs %d: rebuild it (__graft_entry__.build())"
+                              % (LIB_PATH, got, ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

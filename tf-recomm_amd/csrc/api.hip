@@ -299,6 +299,8 @@ static int check_device_error(tfr_model* m) {
         HIPCHK(hipStreamSynchronize(m->stream));
         if (e & 1) return fail(TFR_ERR_OOB, "user/item id out of range [0,%lld) / [0,%lld)",
                                (long long)m->U, (long long)m->I);
+        if (e == 8) return fail(TFR_ERR_OOB, "row-sharded step: another rank voided the step (capacity exceeded or id out of range there) - "
+                                             "it was void on every rank; that rank's sync names the cause");
         if (e & 4) return fail(TFR_ERR_OOB, "row-sharded step: more local samples or distinct items per owner than the fixed capacities "
                                             "(sample_cap / slot_cap) hold - the step was void; raise the slack");
         return fail(TFR_ERR_OOB, "store index out of range [0,%lld)", (long long)m->N);
@@ -349,6 +351,50 @@ int tfr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// ---- measurement yardstick: what a plain float4 read+write copy reaches on this device ---------------------------
+// (MI355X_MICROARCH.md quotes 6.29 TB/s for exactly this shape of kernel; bench.py prints both)
+__global__ void __launch_bounds__(256) k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
+}
+
+int tfr_device_copy_rate(int32_t device, int64_t bytes, int32_t reps, double* best_gbs, double* mean_gbs) {
+    if (bytes < (1 << 20) || reps < 1 || reps > 1000 || !best_gbs) return fail(TFR_ERR_ARG, "tfr_device_copy_rate: bad argument");
+    HIPCHK(hipSetDevice(device));
+    const int64_t n4 = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc(&a, n4 * 16));
+    if (hipMalloc(&b, n4 * 16) != hipSuccess) { (void)hipFree(a); return fail(TFR_ERR_NOMEM, "tfr_device_copy_rate: out of memory"); }
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    (void)hipMemsetAsync(a, 1, n4 * 16, st);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const int grid = 256 * 8;                               // 256 CUs x 8 blocks of 256 threads, grid-stride
+    double best = 0.0, sum = 0.0;
+    for (int r = -2; r < reps; ++r) {
+        (void)hipEventRecord(e0, st);
+        k_copy_f4<<<grid, 256, 0, st>>>(a, b, n4);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r < 0 || ms <= 0.f) continue;
+        const double g = 2.0 * (double)(n4 * 16) / (ms * 1e-3) / 1e9;
+        sum += g;
+        if (g > best) best = g;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    *best_gbs = best;
+    if (mean_gbs) *mean_gbs = sum / reps;
+    return TFR_OK;
 }
 
 int tfr_destroy(tfr_model* m) {
@@ -2132,7 +2178,8 @@ int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t B,
 // item rows are fetched from and their gradients returned to their owners through fixed-capacity
 // exchange buffers laid out [world][slot_cap] rows of tfr_shard_row_stride() floats: D features, the bias, padding.
 
-static int shard_stride(const tfr_model* m) { return m->VEC == 4 ? m->D + 4 : m->D + 1; }
+// floats per exchanged row: features, bias, the sender's error flag, padding to 16 bytes where rows are read as float4
+static int shard_stride(const tfr_model* m) { return m->VEC == 4 ? m->D + 4 : m->D + 2; }
 
 int32_t tfr_shard_row_stride(tfr_model* m) { return m ? shard_stride(m) : 0; }
 
@@ -2265,6 +2312,10 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
     hipStream_t s = m->stream;
     int nblk = 0;
+    // a peer that had to void this step (capacity overflow, id out of range) said so beside its rows: void it here too, before
+    // anything is updated - every rank then skips the same step and reports it at its next sync
+    launch_adopt_peer_err(d_item_rows, (int64_t)(nI / m->rt_world) * DS, m->rt_world, m->D, m->d_err, s);
+    HIPCHK(hipGetLastError());
     {
         // K1 runs inside the item-side reduce, on the rows it has in registers anyway (as in the single-GPU big-table step);
         // a separate k_forward launch cost 68 us of the 464 (world-1 rehearsal)

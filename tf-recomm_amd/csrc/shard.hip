@@ -234,12 +234,16 @@ void launch_route_slots(const RouteArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_route_slots, dim3(nb), dim3(1024), 0, s, a);
 }
 
-// owner side: rows_out[j] = [table[ids[j]] | bias[ids[j]] | pad] (row stride `stride` floats); unused slots (-1) give zeros
+// owner side: rows_out[j] = [table[ids[j]] | bias[ids[j]] | flag | pad] (row stride `stride` floats); unused slots (-1) give
+// zero features.  `flag` = this rank's device error word as the launch found it (bucket / route errors of this step or an
+// earlier, not yet reported one): it travels to every requester with the rows, so that a step one rank must void is void
+// on all of them (k_adopt_peer_err on the receiving side) - no extra collective.
 template <int G, int VEC>
 __global__ __launch_bounds__(256) void k_gather_packed(GatherPackedArgs a) {
     constexpr int GPB = 256 / G;
     const int gl = threadIdx.x % G, d0 = gl * VEC;
     bool oob = false;
+    const float flag = (float)(*a.err != 0);
     for (int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G; j < a.n; j += (int64_t)gridDim.x * GPB) {
         const int32_t id = a.ids[j];
         float* dst = a.out + (size_t)j * a.stride;
@@ -259,9 +263,23 @@ __global__ __launch_bounds__(256) void k_gather_packed(GatherPackedArgs a) {
             if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + d0) = make_float4(v[0], v[1], v[2], v[3]);
             else dst[d0] = v[0];
         }
-        if (gl == 0) dst[a.D] = b;
+        if (gl == 0) {
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + a.D) = make_float4(b, flag, 0.f, 0.f);
+            else { dst[a.D] = b; dst[a.D + 1] = flag; }
+        }
     }
     if (oob) atomicOr(a.err, 1);
+}
+
+// requester side: chunk w of the received rows came from owner w; any owner's flag set -> this rank's step is void too
+__global__ __launch_bounds__(64) void k_adopt_peer_err(const float* rows, int64_t chunk_floats, int32_t world, int32_t D, int32_t* err) {
+    bool any = false;
+    for (int w = threadIdx.x; w < world; w += 64) any |= rows[(size_t)w * chunk_floats + D + 1] != 0.f;
+    if (__ballot(any) && threadIdx.x == 0) atomicOr(err, 8);
+}
+
+void launch_adopt_peer_err(const float* rows, int64_t chunk_floats, int32_t world, int32_t D, int32_t* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_adopt_peer_err, dim3(1), dim3(64), 0, s, rows, chunk_floats, world, D, err);
 }
 
 void launch_gather_packed(const GatherPackedArgs& a, int G, int VEC, hipStream_t s) {

@@ -261,6 +261,8 @@ struct GatherPackedArgs {
     int64_t n, rows; int32_t D, stride;
 };
 void launch_gather_packed(const GatherPackedArgs& a, int G, int VEC, hipStream_t s);
+// the error flags the owners packed beside their rows (float D + 1 of a row; one chunk of `chunk_floats` per owner) -> err |= 8
+void launch_adopt_peer_err(const float* rows, int64_t chunk_floats, int32_t world, int32_t D, int32_t* err, hipStream_t s);
 // pads (-1) of a received request list -> `pad_key` (one past the last row, sorts last); counts the real ones
 void launch_pad_keys(const int32_t* ids_in, int32_t* keys_out, int64_t n, int32_t pad_key, int32_t* count, hipStream_t s);
 

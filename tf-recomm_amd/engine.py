@@ -13,6 +13,14 @@ import numpy as np
 from . import _lib as L
 
 
+def device_copy_rate(device=0, nbytes=1 << 30, reps=10):
+    """(best, mean) GB/s (read + write) of the library's own float4 copy kernel - bench.py's same-device yardstick."""
+    lib = L.load()
+    best, mean = C.c_double(), C.c_double()
+    L.check(lib.tfr_device_copy_rate(int(device), int(nbytes), int(reps), C.byref(best), C.byref(mean)))
+    return best.value, mean.value
+
+
 class SvdModel:
     """The five trainables of ops.py:8-12,29-32 (+ optimiser slots) resident in HBM."""
 

@@ -60,8 +60,8 @@ def shard_range(rows, world, rank):
 
 
 def packed_stride(dim):
-    """floats per exchanged row: the features, the bias, padding to 16 bytes (csrc/api.hip shard_stride)"""
-    return dim + 4 if dim % 4 == 0 else dim + 1
+    """floats per exchanged row: the features, the bias, the sender's error flag, padding to 16 bytes (csrc/api.hip shard_stride)"""
+    return dim + 4 if dim % 4 == 0 else dim + 2
 
 
 class Comm(object):
@@ -458,6 +458,8 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
         phases[name] = phases.get(name, 0.0) + e0.elapsed_time(e1) * 1e3 / min(K, 10)
     m.timers = None
     wire = m.wire_bytes_per_step(Bg) + (world - 1) * m.pair_capacity(B) * 16      # + the sample records
+    m.backend.sync()
+    m.backend.model.close()                              # the shard's HBM goes back before the caller builds anything else
     step_s = elapsed / K
     exch_us = sum(v for k, v in phases.items() if k.startswith("all_to_all"))
     xgmi = wire / step_s / 1e9
