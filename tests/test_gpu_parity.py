@@ -204,6 +204,24 @@ def test_sort_large_random_matches_numpy(B):
     assert np.array_equal(ks, ids[want])
 
 
+@pytest.mark.parametrize("n", [20_000, 300_000, 10_000_000, 2_000_000_000])
+def test_sort_one_launch_per_pass_edges(n):
+    """The batch-sized radix sort (k_rs2_first + one k_rs2_pass per 8-bit digit: tiles of 4096 keys, offsets derived from the
+    per-tile histogram matrix, the next pass's histogram counted by integer atomics) at its edges: 2, 3 and 4 passes, one key,
+    partial waves and tiles, exactly 128 tiles (its limit), one key more (falls back to the three-launch form), heavy duplicates."""
+    rs = np.random.RandomState(n % 1000 + 3)
+    with T.SvdModel(n, n if n <= 10_000_000 else 16, 4, optimizer="sgd") as m:
+        for B in (1, 63, 64, 4095, 4096, 4097, 100_000, 262_144, 524_288, 524_289):
+            ids = rs.randint(0, n, B).astype(np.int32)
+            if B > 1000:                                     # a hot id on a third of the batch + a block of equal keys
+                ids[rs.rand(B) < 0.33] = ids[0]
+                ids[B // 2: B // 2 + 500] = n - 1
+            ks, ps = m.sort_segments(0, ids)
+            want = np.argsort(ids, kind="stable").astype(np.int32)
+            assert np.array_equal(ps, want), (n, B)
+            assert np.array_equal(ks, ids[want]), (n, B)
+
+
 # ------------------------------------------------------------------ determinism
 @pytest.mark.parametrize("opt,mode", [("adam", "tf1"), ("adam", "lazy"), ("sgd", "tf1")])
 def test_run_to_run_bit_identical(opt, mode):
@@ -567,6 +585,94 @@ def test_train_step_large_against_compacted_oracle(opt, mode):
     assert np.array_equal(gP[mask], P[mask]) and np.array_equal(gbu[mask], bu[mask])      # untouched rows never move
     mask = np.ones(I, bool); mask[ui] = False
     assert np.array_equal(gQ[mask], Q[mask])
+
+
+# ------------------------------------------------------------------ two-table form of the fused big-table step
+@pytest.mark.parametrize("opt,mode,item_abs", [("adam", "lazy", False), ("sgd", "tf1", True)])
+def test_two_table_item_rows_settle_before_every_other_reader(opt, mode, item_abs):
+    """The fused big-table step keeps no copy of the pre-update item rows: an updated row goes to the alternate item table and
+    the row's word flips (svd_kernels.h RedArgs::sel).  Everything else that looks at item_features - forward, eval, get /
+    set_table, the row-sharded and data-parallel entry points - must first see every row back in the main table.  Steps and readers are
+    interleaved here and each result is held against the float64 oracle; the same item rows are touched again and again
+    (they flip back and forth), some by runs cut at a block boundary (finished in place by k_apply_rows)."""
+    U, I, D, B = 40000, 30000, 64, 20000
+    rs = np.random.RandomState(31)
+    t = rand_tables(rs, U, I, D, scale=0.15)
+    kw = dict(loss="mse", item_abs=item_abs, reg_bias=False, optimizer=opt, adam_mode=mode, lr=3e-3, reg=0.02)
+    orc = make_oracle(U, I, D, t, **kw)
+    hot = rs.randint(0, I, 400)
+    with model_from(U, I, D, t, **kw) as m:
+        for s in range(5):
+            u = rs.randint(0, U, B).astype(np.int32)
+            i = np.where(rs.rand(B) < 0.6, hot[rs.randint(0, 400, B)], rs.randint(0, I, B)).astype(np.int32)
+            i[rs.rand(B) < 0.1] = hot[0]                             # one run of ~2000 entries: dozens of pieces
+            r = rs.randint(1, 6, B).astype(np.float32)
+            logits, lossv, regv = m.train_step(u, i, r)
+            wl, wloss, wreg = orc.train_step(u, i, r)
+            tol = 2 * RTOL * (s + 1)
+            assert_close(logits, wl, rtol=tol, what="logits step %d" % s)
+            assert_close(lossv, wloss, rtol=tol, what="loss")
+            if s == 1:                                               # a forward between two fused steps
+                fu, fi = rs.randint(0, U, 5000).astype(np.int32), hot[rs.randint(0, 400, 5000)].astype(np.int32)
+                assert_close(m.forward(fu, fi), orc.forward(fu, fi), rtol=tol, what="forward after step 1")
+            if s == 2:                                               # get_table, then put a changed table back
+                q = m.get_table(L.Q)
+                assert_close(q, orc.tables()[L.Q], rtol=(2e-4 if opt == "adam" else 4 * RTOL) * 6, what="Q after step 2")
+                q[hot[:7]] *= np.float32(0.5)
+                m.set_table(L.Q, q)
+                oq = orc.tables()[L.Q]; oq[hot[:7]] = q[hot[:7]].astype(np.float64)
+                orc.set_tables(orc.mu, orc.bu, orc.bi, orc.P, oq)
+            if s == 3:                                               # a tiny batch (a single partly filled block) in between
+                su, si = rs.randint(0, U, 300).astype(np.int32), hot[rs.randint(0, 400, 300)].astype(np.int32)
+                sr = rs.randint(1, 6, 300).astype(np.float32)
+                l2, _, _ = m.train_step(su, si, sr)
+                w2, _, _ = orc.train_step(su, si, sr)
+                assert_close(l2, w2, rtol=tol, what="small-batch step")
+        got = m.tables()
+    for tid in TIDS:
+        assert_close(got[tid], orc.tables()[tid], rtol=(2e-4 if opt == "adam" else 4 * RTOL) * 8, what="table %s" % TABLE_NAMES[tid])
+
+
+_TWO_TABLE_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+import tfrecomm_amd as T
+from tfrecomm_amd import _lib as L
+U, I, D, B = 300000, 50000, 128, 100000
+rs = np.random.RandomState(3)
+with T.SvdModel(U, I, D, optimizer="adam", adam_mode="lazy", lr=2e-3, reg=0.02) as m:
+    m.init_tables(seed=5)
+    N = 400000
+    u = rs.randint(0, U, N).astype(np.int32)
+    i = np.where(rs.rand(N) < 0.3, rs.randint(0, 20, N), rs.randint(0, I, N)).astype(np.int32)
+    m.upload_triples(u, i, rs.randint(1, 6, N).astype(np.float32))
+    np.random.seed(1)
+    m.rng_from_numpy()
+    loss = m.train_steps_drawn(B, 7, want_loss=True)          # look-ahead pipeline, fused steps
+    lg, l1, _ = m.train_step(u[:B], i[:B], np.ones(B, np.float32))
+    h = hashlib.sha256()
+    for tid in (L.MU, L.BU, L.BI, L.P, L.Q, L.Q | L.SLOT_M, L.Q | L.SLOT_V):
+        h.update(np.ascontiguousarray(m.get_table(tid)).tobytes())
+    h.update(loss.tobytes()); h.update(lg.tobytes())
+    print("HASH", h.hexdigest())
+"""
+
+
+def test_two_table_form_is_bit_identical_to_the_copy_form():
+    """TFR_DUALQ=0 restores the per-entry copy of the pre-update item rows.  Both forms add the same numbers in the same order:
+    tables, Adam slots, losses and logits after eight steps (seven through the look-ahead pipeline) hash identically."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, TFR_DUALQ=flag)
+        p = subprocess.run([sys.executable, "-c", _TWO_TABLE_SCRIPT % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        out.append([l for l in p.stdout.decode().splitlines() if l.startswith("HASH")][0])
+    assert out[0] == out[1]
 
 
 # ------------------------------------------------------------------ BASELINE config 3 at its true size

@@ -62,6 +62,10 @@ struct tfr_model {
     int32_t *lrank_u = nullptr, *lrank_i = nullptr, *hist_u = nullptr, *hist_i = nullptr;   // csort
     int32_t *offs_u = nullptr, *offs_i = nullptr, *binbase_u = nullptr, *binbase_i = nullptr;
     int32_t *blocktot_u = nullptr, *blocktot_i = nullptr;
+    // two-table form of the fused big-table step (RedArgs::sel): the alternate item table, the per-row "which table" word,
+    // the per-entry {partner row | old table} words of the current batch; q_dirty = some row may live in q_alt
+    float* q_alt = nullptr; int32_t* q_sel = nullptr; int32_t* osel = nullptr; bool q_dirty = false;
+    int32_t* rs2_hist = nullptr;      // rsort2: [RS2_MAX_PASSES][2][256 * RS2_MAX_TILES] per-tile digit histograms
     bool csort_ok = false;
     float *gq = nullptr, *gp = nullptr, *gbq = nullptr, *gbp = nullptr;
     int32_t *map_u = nullptr, *map_i = nullptr;
@@ -194,6 +198,8 @@ static void free_workspace(tfr_model* m) {
     dfree(m->partials); dfree(m->lrank_u); dfree(m->lrank_i); dfree(m->hist_u); dfree(m->hist_i);
     dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
     dfree(m->blocktot_u); dfree(m->blocktot_i);
+    dfree(m->rs2_hist); m->rs2_hist = nullptr;
+    dfree(m->osel); m->osel = nullptr;
     for (int pz = 0; pz < 2; ++pz) for (int sd = 0; sd < 2; ++sd) { dfree(m->srt[pz][sd]); m->srt[pz][sd] = nullptr; }
     dfree(m->d_in); m->d_in = nullptr;
     if (m->h_in) (void)hipHostFree(m->h_in);
@@ -256,6 +262,7 @@ static int ensure_capacity(tfr_model* m, int64_t B) {
         const bool small = (1 << (m->bits_u > m->bits_i ? m->bits_u : m->bits_i)) <= CSORT_MAX_BINS;
         const size_t hu = (small ? ((size_t)1 << m->bits_u) : 256) * ntiles;
         const size_t hi = (small ? ((size_t)1 << m->bits_i) : 256) * ntiles;
+        if ((rc = dmalloc(&m->osel, cap))) return rc;
         if ((rc = dmalloc(&m->lrank_u, cap))) return rc;
         if ((rc = dmalloc(&m->lrank_i, cap))) return rc;
         if ((rc = dmalloc(&m->hist_u, hu > 256 * ntiles ? hu : 256 * ntiles))) return rc;
@@ -404,6 +411,7 @@ int tfr_destroy(tfr_model* m) {
     for (auto& e : m->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     free_workspace(m);
     for (int t = 0; t < 5; ++t) { dfree(m->w[t]); dfree(m->m[t]); dfree(m->v[t]); }
+    dfree(m->q_alt); dfree(m->q_sel);
     dfree(m->map_u); dfree(m->map_i); dfree(m->dg_p); dfree(m->dg_q); dfree(m->dg_bu); dfree(m->dg_bi); dfree(m->scalars); dfree(m->step_out); dfree(m->d_err);
     dfree(m->store); dfree(m->d_auc);
     dfree(m->d_ids); dfree(m->ev_u); dfree(m->ev_i); dfree(m->ev_r);
@@ -522,10 +530,21 @@ int tfr_create(tfr_model** out, int64_t U, int64_t I, int32_t D, const tfr_opts*
 }
 
 // ---- variables -------------------------------------------------------------------------
+// two-table form: every row that lives in the alternate item table goes back to the main one.  Called by everything that
+// looks at item_features other than the fused big-table step itself (forward / eval, get / set, the other step paths).
+static int settle_q(tfr_model* m) {
+    if (!m->q_dirty) return TFR_OK;
+    launch_settle_alt(m->w[TFR_Q], m->q_alt, m->q_sel, m->I, m->D, m->stream);
+    HIPCHK(hipGetLastError());
+    m->q_dirty = false;
+    return TFR_OK;
+}
+
 static int table_ptr(tfr_model* m, int32_t which, float** p, int64_t* n) {
     const int t = which & 7;
     if (t > TFR_Q || (which & ~(7 | TFR_SLOT_M | TFR_SLOT_V)) || ((which & TFR_SLOT_M) && (which & TFR_SLOT_V)))
         return fail(TFR_ERR_ARG, "bad table id %d", which);
+    if (t == TFR_Q && settle_q(m)) return TFR_ERR_HIP;
     float* q = (which & TFR_SLOT_M) ? m->m[t] : (which & TFR_SLOT_V) ? m->v[t] : m->w[t];
     if (!q) return fail(TFR_ERR_STATE, "table %d has no such slot (optimizer is not Adam)", which);
     *p = q;
@@ -668,6 +687,7 @@ int tfr_profile_read(tfr_model* m, int32_t kernel, double* total_ms, int64_t* la
 static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t* di, const float* dr,
                        int64_t B, float* d_logits, float* d_g, int* nblk_out,
                        const int64_t* d_store_ids = nullptr) {
+    { const int rcq = settle_q(m); if (rcq) return rcq; }
     FwdArgs a;
     memset(&a, 0, sizeof(a));
     a.P = m->w[TFR_P]; a.Q = m->w[TFR_Q]; a.bu = m->w[TFR_BU]; a.bi = m->w[TFR_BI]; a.mu = m->w[TFR_MU];
@@ -700,6 +720,31 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
     const int passes = (maxbits + 7) / 8;
     int32_t* tmpk[2] = {m->ks2_u, m->ks2_i};
     int32_t* tmpv[2] = {m->ps2_u, m->ps2_i};
+    static int use_rs2 = -1;                             // TFR_RSORT2=0: the three-launches-per-pass form, kept for A/B
+    if (use_rs2 < 0) { const char* e = getenv("TFR_RSORT2"); use_rs2 = (e && e[0] == '0') ? 0 : 1; }
+    if (use_rs2 && rsort2_eligible(B) && passes <= RS2_MAX_PASSES) {
+        int rc;
+        if (!m->rs2_hist && (rc = dmalloc(&m->rs2_hist, (size_t)RS2_MAX_PASSES * 2 * 256 * RS2_MAX_TILES))) return rc;
+        RSort2Args a;
+        memset(&a, 0, sizeof(a));
+        a.B = B; a.passes = passes; a.ntiles = (int32_t)((B + 4095) / 4096);
+        for (int c = 0; c < ncols; ++c) {
+            a.keys_in[c] = keys[c];
+            a.keys_fin[c] = ks_out[c]; a.vals_fin[c] = ps_out[c];
+            a.keys_tmp[c] = tmpk[c]; a.vals_tmp[c] = tmpv[c];
+            a.limit[c] = limits ? (int32_t)limits[c] : 0x7fffffff;
+            for (int p = 0; p < RS2_MAX_PASSES; ++p) a.hist[p][c] = m->rs2_hist + ((size_t)p * 2 + c) * 256 * RS2_MAX_TILES;
+        }
+        a.err = limits ? m->d_err : nullptr;             // ids outside the tables void the step
+        if (store_ids) {                                 // the first launch gathers the batch from the resident store itself
+            a.ids = store_ids; a.store = m->store; a.N = m->N;
+            a.u_out = m->d_u; a.i_out = m->d_i; a.r_out = m->d_r;
+            a.err = m->d_err;
+        }
+        launch_rsort2(a, ncols, m->stream);
+        HIPCHK(hipGetLastError());
+        return TFR_OK;
+    }
     RSortArgs r;
     memset(&r, 0, sizeof(r));
     r.B = B;
@@ -954,6 +999,15 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         int rc;
         tiles = tiles_eligible(m, B);
         const bool fwd_fused = fwd_in_reduce(m, B);
+        // two-table form of the fused big-table step (no per-entry copy of the pre-update item rows): TFR_DUALQ=0 restores the copy
+        static int dualq = -1;
+        if (dualq < 0) { const char* e = getenv("TFR_DUALQ"); dualq = (e && e[0] == '0') ? 0 : 1; }
+        const bool dual = fwd_fused && dualq;
+        if (dual && !m->q_alt) {
+            if ((rc = dmalloc(&m->q_alt, (size_t)m->n[TFR_Q])) || (rc = dmalloc(&m->q_sel, (size_t)m->I))) return rc;
+            HIPCHK(hipMemsetAsync(m->q_sel, 0, (size_t)m->I * 4, s));
+        }
+        if (!dual && (rc = settle_q(m))) return rc;
         static int split_tiles = -1;   // TFR_TILE_SPLIT=1: the three-launch form (k_front + k_seg_reduce), kept for A/B
         if (split_tiles < 0) { const char* e = getenv("TFR_TILE_SPLIT"); split_tiles = (e && e[0] == '1') ? 1 : 0; }
         const bool one_launch = tiles && !split_tiles;
@@ -1058,8 +1112,16 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             ri.own_w = m->w[TFR_Q]; ri.m = m->m[TFR_Q]; ri.v = m->v[TFR_Q];
             ri.bias_w = m->w[TFR_BI]; ri.bias_m = m->m[TFR_BI]; ri.bias_v = m->v[TFR_BI];
             ri.frozen_rows = (m->frozen >> TFR_Q) & 1; ri.frozen_bias = (m->frozen >> TFR_BI) & 1;
-            ri.own_copy_out = qcopy;
-            ru.partner_by_pos = qcopy;
+            if (dual) {
+                // the updated item row goes to the table the row is NOT in, so the user side still finds the pre-update row where
+                // it was: no copy written (4D per rating) and none read
+                ri.own_alt = m->q_alt; ri.own_w_alt = m->q_alt; ri.sel = m->q_sel; ri.osel_out = m->osel;
+                ru.osel_in = m->osel; ru.partner_alt = m->q_alt;
+                m->q_dirty = true;
+            } else {
+                ri.own_copy_out = qcopy;
+                ru.partner_by_pos = qcopy;
+            }
             ru.grad_rows = m->gq + (size_t)m->cap * m->D;
             if (fwd_fused) {           // K1 inside the item side: logits, g, per-block {loss, reg, sum g}
                 ri.partner_bias = m->w[TFR_BU]; ri.mu = m->w[TFR_MU]; ri.r = dr; ri.loss = o.loss;
@@ -1092,6 +1154,7 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
             app.a[0].w = m->w[TFR_Q]; app.a[0].m = m->m[TFR_Q]; app.a[0].v = m->v[TFR_Q];
             app.a[0].bias_w = m->w[TFR_BI]; app.a[0].bias_m = m->m[TFR_BI]; app.a[0].bias_v = m->v[TFR_BI];
             app.a[0].frozen_rows = ri.frozen_rows; app.a[0].frozen_bias = ri.frozen_bias;
+            if (dual) { app.a[0].w_alt = m->q_alt; app.a[0].sel = m->q_sel; }
             app.a[1] = ap;
             app.a[1].ks = m->ks_u; app.a[1].grad_rows = ru.grad_rows; app.a[1].grad_bias = m->gbp;
             app.a[1].w = m->w[TFR_P]; app.a[1].m = m->m[TFR_P]; app.a[1].v = m->v[TFR_P];
@@ -1518,6 +1581,10 @@ int tfr_set_triples_dev(tfr_model* m, const int32_t* du, const int32_t* di, cons
 int tfr_init_tables(tfr_model* m, uint64_t seed, float fstd, float bstd) {
     MODEL_ENTER(m);
     hipStream_t s = m->stream;
+    if (m->q_dirty) {                                    // fresh tables: every row lives in the main table again
+        HIPCHK(hipMemsetAsync(m->q_sel, 0, (size_t)m->I * 4, s));
+        m->q_dirty = false;
+    }
     launch_init_trunc_normal(m->w[TFR_P], m->n[TFR_P], fstd, seed * 4 + 0, s);
     launch_init_trunc_normal(m->w[TFR_Q], m->n[TFR_Q], fstd, seed * 4 + 1, s);
     launch_init_trunc_normal(m->w[TFR_BU], m->n[TFR_BU], bstd, seed * 4 + 2, s);
@@ -2055,7 +2122,7 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
                  tile_step_epg((int)ntiles, G, V), G, V, nt);
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
-        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
+        snprintf(tmp, sizeof(tmp), "sort=k_rs2_first (gathers the batch) + k_rs2_pass x%d;reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
                  "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
                  ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
     } else if (csort) {
@@ -2288,6 +2355,7 @@ int tfr_shard_gather(tfr_model* m, const int32_t* d_req_recv, int64_t n, float* 
     MODEL_ENTER(m);
     if (n < 0 || (n > 0 && (!d_req_recv || !d_rows_out))) return fail(TFR_ERR_ARG, "shard_gather: bad arguments");
     if (n == 0) return TFR_OK;
+    { const int rcq = settle_q(m); if (rcq) return rcq; }
     GatherPackedArgs g;
     g.ids = d_req_recv; g.table = m->w[TFR_Q]; g.bias = m->w[TFR_BI]; g.out = d_rows_out; g.err = m->d_err;
     g.n = n; g.rows = m->I; g.D = m->D; g.stride = shard_stride(m);
@@ -2422,6 +2490,7 @@ int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* 
     if (n < 0 || (n > 0 && (!d_req_recv || !d_grad_recv))) return fail(TFR_ERR_ARG, "shard_apply_items: bad arguments");
     if (!m->rt_counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
     int rc;
+    if ((rc = settle_q(m))) return rc;
     if ((rc = ensure_capacity(m, n > 0 ? n : 1))) return rc;
     const tfr_opts& o = m->o;
     const bool adam = o.optimizer == TFR_OPT_ADAM;
@@ -2540,6 +2609,7 @@ int tfr_dp_local_grads(tfr_model* m, const int32_t* du, const int32_t* di, const
     if (o.optimizer == TFR_OPT_ADAM && o.adam_mode != TFR_ADAM_TF1)
         return fail(TFR_ERR_STATE, "data-parallel steps need dense semantics: Adam tf1 or SGD");
     int rc;
+    if ((rc = settle_q(m))) return rc;
     const int64_t* next_ids = d_store_ids ? m->dp_next_ids : nullptr;     // one-shot hint (tfr_dp_hint_next)
     m->dp_next_ids = nullptr;
     if ((rc = ensure_capacity(m, B > 0 ? B : 1))) return rc;
@@ -2634,6 +2704,7 @@ int tfr_dp_apply(tfr_model* m, float* d_flat) {
     if (adam && o.adam_mode != TFR_ADAM_TF1)
         return fail(TFR_ERR_STATE, "data-parallel steps need dense semantics: Adam tf1 or SGD");
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
+    { const int rcq = settle_q(m); if (rcq) return rcq; }
     float* gP = d_flat;
     float* gQ = gP + m->U * m->D;
     float* gbu = gQ + m->I * m->D;

@@ -45,6 +45,12 @@ struct RedArgs {
     const float* lam_arr;                          // optional per-entry coefficient of the own row (FM)
     float* own_copy_out;                           // optional [B,D]: the entry's pre-update own row, by batch position
     const float* partner_by_pos;                   // optional [B,D]: read the partner row from such a copy instead
+    // two-table form of the fused big-table step (no pre-update copy): an item row lives in `own` or in `own_alt`, sel[row] says
+    // which.  Item side: reads the current one, writes the updated row into the OTHER table and flips sel[row] (whole runs; runs
+    // cut by a block boundary stay where they are, k_apply_rows finishes them in place), and leaves osel_out[pos] = row | cur << 31.
+    // User side: osel_in[pos] gives the partner row id and the table that still holds its pre-update value.
+    const float* own_alt; float* own_w_alt; int32_t* sel; int32_t* osel_out;
+    const int32_t* osel_in; const float* partner_alt;
     // forward fused into this side (FWD kernels): logits, g and the per-block {loss, reg, sum g}
     // are produced here from the rows the reduce loads anyway
     const float* partner_bias; const float* mu; const float* r;
@@ -81,6 +87,7 @@ struct ApplyArgs {
     float alpha, b1, b2, eps, lr;
     const int32_t* dB;                             // row-sharded step: entries actually present (<= B)
     int32_t wstride, wbstride;                     // OPT 2 (emit reduced rows): output row / bias stride (0 = D / 1)
+    float* w_alt; const int32_t* sel;              // two-table form: the row is updated in place in the table sel[row] names
 };
 struct FinArgs {
     const float* partials; int32_t nblk;
@@ -279,6 +286,7 @@ void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rn
 // sort.hip
 constexpr int CSORT_TILE = 1024;
 constexpr int CSORT_MAX_BINS = 16384;          // 64 KB of LDS counters
+void launch_settle_alt(float* main_t, const float* alt_t, int32_t* sel, int64_t rows, int D, hipStream_t s);
 bool csort_eligible(int64_t B, int bits_u, int bits_i);
 void launch_csort(const CSortArgs& a, const FinArgs* fin, hipStream_t s);   // fin: run K4 in the scan launch
 // LSD radix sort pass (8-bit digit at `shift`) over up to two key columns
@@ -295,5 +303,21 @@ struct RSortArgs {
     const int64_t* ids; const int4* store; int64_t N; float* r_out; int32_t* u_out; int32_t* i_out;
 };
 void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s);
+
+// rsort2 (sort.hip): the radix sort of a training batch in 1 + passes launches; tiles of 4096 keys, at most RS2_MAX_TILES
+constexpr int RS2_MAX_TILES = 128;
+constexpr int RS2_MAX_PASSES = 4;
+struct RSort2Args {
+    const int32_t* keys_in[2];                               // pass 0 input (unless ids != NULL)
+    int32_t* keys_fin[2]; int32_t* vals_fin[2];              // where the sorted keys / positions must end up
+    int32_t* keys_tmp[2]; int32_t* vals_tmp[2];              // ping-pong partner
+    int32_t* hist[RS2_MAX_PASSES][2];                        // [256 * ntiles] per pass and column, bin-major
+    int32_t passes, ntiles;
+    int64_t B;
+    int32_t limit[2]; int32_t* err;                          // err != NULL: keys outside [0, limit) flag |= 1
+    const int64_t* ids; const int4* store; int64_t N; float* r_out; int32_t* u_out; int32_t* i_out;   // fused gather (pass 0)
+};
+bool rsort2_eligible(int64_t B);
+void launch_rsort2(const RSort2Args& a, int ncols, hipStream_t s);
 
 }  // namespace tfr

@@ -917,6 +917,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 
     Frag<VEC> o, t, mrow, vrow;
     float ob = 0.f, tb = 0.f, mb = 0.f, vb = 0.f;
+    int32_t cur = 0;                                     // two-table form: the table this entry's own row is in
     float facc[3] = {0.f, 0.f, 0.f};                     // FWD: this lane's {loss, reg, g} share
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { o.v[q] = 0.f; t.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
@@ -938,11 +939,17 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     } else if (valid) {
         float gk = 0.f;
         if constexpr (!FWD) gk = a.g[pos];
-        const int32_t pid = a.partner_by_pos ? 0 : a.other[pos];     // not needed when the partner row comes by position
+        int32_t pid = a.partner_by_pos ? 0 : (a.osel_in ? a.osel_in[pos] : a.other[pos]);   // not needed when the partner row comes by position
+        const float* ptab = a.partner;
+        if (a.osel_in) { if (pid < 0) ptab = a.partner_alt; pid &= 0x7fffffff; }   // the table that still holds the pre-update row
         const float lam_e = a.lam_arr ? a.lam_arr[pos] : a.lam;      // FM: lam - g x^2 per non-zero
         const Frag<VEC> x = a.partner_by_pos ? load_frag_h<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D, a.nt & 8)
-                                             : load_frag_h<VEC>(a.partner + (size_t)pid * (a.pstride ? a.pstride : D), d0, D, a.nt & 1);
-        o = load_frag_h<VEC>(a.own + ooff, d0, D, a.nt & 2);
+                                             : load_frag_h<VEC>(ptab + (size_t)pid * (a.pstride ? a.pstride : D), d0, D, a.nt & 1);
+        if (a.sel) {                                                 // two-table form: which table holds this row now
+            cur = a.sel[row];
+            if (gl == 0) a.osel_out[pos] = row | (cur << 31);
+        }
+        o = load_frag_h<VEC>((cur ? a.own_alt : a.own) + ooff, d0, D, a.nt & 2);
         ob = a.own_bias[oboff];
         if constexpr (RMODE == RMODE_ADAM) {
             if (head) {
@@ -1052,10 +1059,12 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         if (!a.frozen_rows) {
             // FWD variant: the own row is re-read here (an L2 hit) rather than kept live across the walk -
             // four registers that decide whether two blocks fit a CU
-            Frag<VEC> w = (FWD && LEAN) ? load_frag<VEC>(a.own_w + roff, d0, D) : o;
+            Frag<VEC> w = (FWD && LEAN) ? load_frag<VEC>((cur ? a.own_w_alt : a.own_w) + roff, d0, D) : o;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], acc.v[q], c);
-            store_frag_h<VEC>(a.own_w + roff, d0, D, w, a.nt & 4);
+            // two-table form: the new row goes to the other table (the user side still reads the old one), then the row flips
+            store_frag_h<VEC>(((a.sel && !cur) ? a.own_w_alt : a.own_w) + roff, d0, D, w, a.nt & 4);
+            if (a.sel && gl == 0) a.sel[row] = cur ^ 1;
             store_frag_h<VEC>(a.m + roff, d0, D, mrow, a.nt & 4);
             store_frag_h<VEC>(a.v + roff, d0, D, vrow, a.nt & 4);
         }
@@ -1071,7 +1080,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             Frag<VEC> w = o;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * acc.v[q];
-            store_frag<VEC>(a.own_w + roff, d0, D, w);
+            store_frag<VEC>(((a.sel && !cur) ? a.own_w_alt : a.own_w) + roff, d0, D, w);
+            if (a.sel && gl == 0) a.sel[row] = cur ^ 1;
         }
         if (gl == 0 && !a.frozen_bias) a.bias_w[row] = ob - a.lr * gb;
     }
@@ -1190,9 +1200,11 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
     for (int q = 0; q < VEC; ++q) { w.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; gr.v[q] = 0.f; }
     float gb = 0.f;
     long long next = -1;
+    float* wtab = a.w;
     if (own) {
+        if (a.sel && a.sel[row]) wtab = a.w_alt;          // two-table form: finish the row where it lives
         if (OPT != 2 && !a.frozen_rows) {                // issued before the piece walk
-            w = load_frag<VEC>(a.w + roff, d0, D);
+            w = load_frag<VEC>(wtab + roff, d0, D);
             if constexpr (OPT == 0) {
                 mrow = load_frag<VEC>(a.m + roff, d0, D);
                 vrow = load_frag<VEC>(a.v + roff, d0, D);
@@ -1249,7 +1261,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * gr.v[q];
         }
-        store_frag<VEC>(a.w + roff, d0, D, w);
+        store_frag<VEC>(wtab + roff, d0, D, w);
     }
     if (gl == 0 && !a.frozen_bias) {
         float bw = a.bias_w[row];
@@ -1808,6 +1820,25 @@ void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, 
 
 void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s) {
     hipLaunchKernelGGL(k_init_uniform_scalar, dim3(1), dim3(1), 0, s, p, lo, hi, seed);
+}
+
+// two-table form of the big-table step: bring every row that currently lives in the alternate table back to the main
+// one (one wave per row; run before anything but the fused step looks at the item table)
+__global__ __launch_bounds__(256) void k_settle_alt(float* __restrict__ main_t, const float* __restrict__ alt_t,
+                                                    int32_t* __restrict__ sel, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        if (!sel[r]) continue;                            // wave-uniform
+        for (int d = lane; d < D; d += 64) main_t[(size_t)r * D + d] = alt_t[(size_t)r * D + d];
+        if (lane == 0) sel[r] = 0;
+    }
+}
+
+void launch_settle_alt(float* main_t, const float* alt_t, int32_t* sel, int64_t rows, int D, hipStream_t s) {
+    int64_t nb = (rows + 3) / 4;
+    if (nb > 16384) nb = 16384;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_settle_alt, dim3((int)nb), dim3(256), 0, s, main_t, alt_t, sel, rows, D);
 }
 
 void launch_finalize(const FinArgs& a, hipStream_t s) {
