@@ -242,6 +242,11 @@ int tfr_shard_gather(tfr_model* m, const int32_t* d_req_recv, int64_t n, float* 
 int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows /* [world * slot_cap, stride] */,
                              float* d_logits /* [sample_cap], may be NULL */, float* d_item_grad /* out, same layout */,
                              float* d_scalars4 /* out: loss, reg, sum_g, - */);
+/* the same step in two halves, so that a caller can run the user half BESIDE the gradient exchange (it reads the fetched rows and
+ * the local user rows only): tfr_shard_forward_items = sort + forward + item-side reduce into d_item_grad + the local scalars;
+ * tfr_shard_reduce_users = user-side reduce + optimiser on the local user rows.  forward_reduce == forward_items; reduce_users. */
+int tfr_shard_forward_items(tfr_model* m, const float* d_item_rows, float* d_logits, float* d_item_grad, float* d_scalars4);
+int tfr_shard_reduce_users(tfr_model* m, const float* d_item_rows);
 int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* d_grad_recv, int64_t n);
 int tfr_shard_finish_step(tfr_model* m, const float* d_scalars4 /* global sums */);
 

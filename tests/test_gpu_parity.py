@@ -204,13 +204,13 @@ def test_sort_large_random_matches_numpy(B):
     assert np.array_equal(ks, ids[want])
 
 
-@pytest.mark.parametrize("n", [20_000, 300_000, 10_000_000, 2_000_000_000])
+@pytest.mark.parametrize("n", [20_000, 300_000, 10_000_000, 20_000_000])
 def test_sort_one_launch_per_pass_edges(n):
     """The batch-sized radix sort (k_rs2_first + one k_rs2_pass per 8-bit digit: tiles of 4096 keys, offsets derived from the
     per-tile histogram matrix, the next pass's histogram counted by integer atomics) at its edges: 2, 3 and 4 passes, one key,
     partial waves and tiles, exactly 128 tiles (its limit), one key more (falls back to the three-launch form), heavy duplicates."""
     rs = np.random.RandomState(n % 1000 + 3)
-    with T.SvdModel(n, n if n <= 10_000_000 else 16, 4, optimizer="sgd") as m:
+    with T.SvdModel(n, 16, 4, optimizer="sgd") as m:                # 15, 19, 24 and 25 key bits
         for B in (1, 63, 64, 4095, 4096, 4097, 100_000, 262_144, 524_288, 524_289):
             ids = rs.randint(0, n, B).astype(np.int32)
             if B > 1000:                                     # a hot id on a third of the batch + a block of equal keys

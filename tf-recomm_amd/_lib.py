@@ -99,6 +99,8 @@ SIGNATURES = {
     "tfr_shard_routed_devptrs": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "tfr_shard_gather": (C.c_int, [_p, _p, C.c_int64, _p]),
     "tfr_shard_forward_reduce": (C.c_int, [_p, _p, _p, _p, _p]),
+    "tfr_shard_forward_items": (C.c_int, [_p, _p, _p, _p, _p]),
+    "tfr_shard_reduce_users": (C.c_int, [_p, _p]),
     "tfr_shard_apply_items": (C.c_int, [_p, _p, _p, C.c_int64]),
     "tfr_shard_finish_step": (C.c_int, [_p, _p]),
     "tfr_dp_flat_size": (C.c_int64, [_p]),

@@ -2364,10 +2364,11 @@ int tfr_shard_gather(tfr_model* m, const int32_t* d_req_recv, int64_t n, float* 
     return TFR_OK;
 }
 
-int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_logits, float* d_item_grad, float* d_scalars4) {
-    MODEL_ENTER(m);
+// part: 1 = the item half (sort, forward + item-side reduce into the exchange buffer, local scalars), 2 = the user half (user-side
+// reduce + apply; needs nothing the gradient exchange touches, so a caller may run it beside that exchange), 3 = both
+static int shard_forward_reduce_part(tfr_model* m, const float* d_item_rows, float* d_logits, float* d_item_grad, float* d_scalars4, int part) {
     if (!m->rt_counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
-    if (!d_item_rows || !d_item_grad || !d_scalars4) return fail(TFR_ERR_ARG, "shard_forward_reduce: null pointer");
+    if (!d_item_rows || ((part & 1) && (!d_item_grad || !d_scalars4))) return fail(TFR_ERR_ARG, "shard_forward_reduce: null pointer");
     const int64_t B = m->rt_B, nI = m->rt_slots;
     const int DS = shard_stride(m);
     const int32_t* du = m->rt_u; const int32_t* dslot = m->rt_slot; const float* dr = m->rt_r;
@@ -2379,15 +2380,25 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
     const bool tf1 = adam && o.adam_mode == TFR_ADAM_TF1;
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
     hipStream_t s = m->stream;
-    int nblk = 0;
-    // a peer that had to void this step (capacity overflow, id out of range) said so beside its rows: void it here too, before
-    // anything is updated - every rank then skips the same step and reports it at its next sync
-    launch_adopt_peer_err(d_item_rows, (int64_t)(nI / m->rt_world) * DS, m->rt_world, m->D, m->d_err, s);
-    HIPCHK(hipGetLastError());
-    {
+    int nblk = (int)((B + 1024 / m->G - 1) / (1024 / m->G));
+    RedArgs r;
+    memset(&r, 0, sizeof(r));
+    r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D; r.dB = dB;
+    r.item_abs = o.item_abs; r.reg_bias = o.reg_bias;
+    r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
+    RedPair pr;
+    ApplyArgs ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.err = m->d_err; ap.B = B; ap.D = m->D; ap.dB = dB;
+    ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
+    ApplyPair app;
+    if (part & 1) {
+        // a peer that had to void this step (capacity overflow, id out of range) said so beside its rows: void it here too, before
+        // anything is updated - every rank then skips the same step and reports it at its next sync
+        launch_adopt_peer_err(d_item_rows, (int64_t)(nI / m->rt_world) * DS, m->rt_world, m->D, m->d_err, s);
+        HIPCHK(hipGetLastError());
         // K1 runs inside the item-side reduce, on the rows it has in registers anyway (as in the single-GPU big-table step);
         // a separate k_forward launch cost 68 us of the 464 (world-1 rehearsal)
-        nblk = (int)((B + 1024 / m->G - 1) / (1024 / m->G));
         {
             Prof p(m, TFR_K_SORT);                        // unused sample slots carry keys one past the last row: they sort last
             const int32_t* keys[2] = {du, dslot};
@@ -2396,12 +2407,6 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
             int32_t* ps[2] = {m->ps_u, m->ps_i};
             if ((rc = radix_sort_columns(m, 2, keys, bits, ks, ps, B))) return rc;
         }
-        RedArgs r;
-        memset(&r, 0, sizeof(r));
-        r.g = m->d_g; r.err = m->d_err; r.B = B; r.D = m->D; r.dB = dB;
-        r.item_abs = o.item_abs; r.reg_bias = o.reg_bias;
-        r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
-        RedPair pr;
         RedArgs ri = r;                 // item side: own = the fetched rows, indexed by slot
         ri.side = 1;
         ri.ks = m->ks_i; ri.ps = m->ps_i; ri.other = du;
@@ -2418,11 +2423,6 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
             launch_seg_reduce(pr, 1, RMODE_SCRATCH, m->G, m->VEC, s, true);
         }
         HIPCHK(hipGetLastError());
-        ApplyArgs ap;
-        memset(&ap, 0, sizeof(ap));
-        ap.err = m->d_err; ap.B = B; ap.D = m->D; ap.dB = dB;
-        ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
-        ApplyPair app;
         app.a[0] = ap;                  // reduced gradient row (+ bias gradient) of the split slots, in the exchange layout
         app.a[0].only_split = 1;
         app.a[0].ks = m->ks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
@@ -2432,6 +2432,17 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
             launch_apply_rows(app, 1, 2, m->G, m->VEC, s);
         }
         HIPCHK(hipGetLastError());
+        FinArgs f;                      // local {loss, reg, sum g}; bias_global waits for the all-reduce
+        memset(&f, 0, sizeof(f));
+        f.partials = m->partials; f.nblk = nblk; f.scalars = m->scalars; f.out = d_scalars4; f.err = m->d_err;
+        f.mu = m->w[TFR_MU];
+        {
+            Prof p(m, TFR_K_FINALIZE);
+            launch_finalize(f, s);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (part & 2) {
         RedArgs ru = r;                 // user side: rows are local; partner = fetched item rows
         ru.side = 0;
         ru.ks = m->ks_u; ru.ps = m->ps_u; ru.other = dslot;
@@ -2459,7 +2470,7 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
         }
         HIPCHK(hipGetLastError());
     }
-    if (tf1) {                          // dense sweep of the local user rows (every row moves)
+    if (tf1 && (part & 2)) {            // dense sweep of the local user rows (every row moves)
         DensePair dp;
         memset(&dp, 0, sizeof(dp));
         DenseArgs& d = dp.a[0];
@@ -2473,16 +2484,22 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_lo
         launch_adam_dense(dp, 1, m->G, m->VEC, s);
         HIPCHK(hipGetLastError());
     }
-    FinArgs f;                          // local {loss, reg, sum g}; bias_global waits for the all-reduce
-    memset(&f, 0, sizeof(f));
-    f.partials = m->partials; f.nblk = nblk; f.scalars = m->scalars; f.out = d_scalars4; f.err = m->d_err;
-    f.mu = m->w[TFR_MU];
-    {
-        Prof p(m, TFR_K_FINALIZE);
-        launch_finalize(f, s);
-    }
-    HIPCHK(hipGetLastError());
     return TFR_OK;
+}
+
+int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows, float* d_logits, float* d_item_grad, float* d_scalars4) {
+    MODEL_ENTER(m);
+    return shard_forward_reduce_part(m, d_item_rows, d_logits, d_item_grad, d_scalars4, 3);
+}
+
+int tfr_shard_forward_items(tfr_model* m, const float* d_item_rows, float* d_logits, float* d_item_grad, float* d_scalars4) {
+    MODEL_ENTER(m);
+    return shard_forward_reduce_part(m, d_item_rows, d_logits, d_item_grad, d_scalars4, 1);
+}
+
+int tfr_shard_reduce_users(tfr_model* m, const float* d_item_rows) {
+    MODEL_ENTER(m);
+    return shard_forward_reduce_part(m, d_item_rows, nullptr, nullptr, nullptr, 2);
 }
 
 int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* d_grad_recv, int64_t n) {

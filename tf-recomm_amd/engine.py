@@ -325,6 +325,12 @@ class SvdModel:
     def shard_forward_reduce(self, d_item_rows, d_logits, d_item_grad, d_scalars4):
         L.check(self._lib.tfr_shard_forward_reduce(self._h, d_item_rows, d_logits, d_item_grad, d_scalars4))
 
+    def shard_forward_items(self, d_item_rows, d_logits, d_item_grad, d_scalars4):
+        L.check(self._lib.tfr_shard_forward_items(self._h, d_item_rows, d_logits, d_item_grad, d_scalars4))
+
+    def shard_reduce_users(self, d_item_rows):
+        L.check(self._lib.tfr_shard_reduce_users(self._h, d_item_rows))
+
     def shard_apply_items(self, d_req_recv, d_grad_recv, n):
         L.check(self._lib.tfr_shard_apply_items(self._h, d_req_recv, d_grad_recv, n))
 

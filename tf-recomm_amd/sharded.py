@@ -86,6 +86,15 @@ class Comm(object):
             dist.all_to_all_single(out, inp, group=self.group)
         return out
 
+    def all_to_all_start(self, inp, out=None):
+        """the same exchange, started without making the caller's stream wait for it: returns (out, work); ``work.wait()`` (or
+        None with the staged CPU backend, which has already finished) orders the current stream behind the exchange"""
+        if self.stage or not inp.is_cuda:
+            return self.all_to_all(inp, out), None
+        if out is None:
+            out = torch.empty_like(inp)
+        return out, dist.all_to_all_single(out, inp, group=self.group, async_op=True)
+
     def all_reduce_sum(self, t):
         if self.stage and t.is_cuda:
             c = t.cpu()
@@ -206,6 +215,23 @@ class HipShard(object):
         self.model.shard_forward_reduce(item_rows.data_ptr(), logits.data_ptr(), grad.data_ptr(), scal.data_ptr())
         self._sync_out()
         return grad, scal, logits
+
+    def forward_items(self, item_rows):
+        """the item half of forward_reduce: sort, forward + item-side reduce into the exchange buffer, local scalars"""
+        cap, _ = self._routed
+        grad = self._get("grad", tuple(item_rows.shape), torch.float32)
+        logits = self._get("logits", (cap,), torch.float32)
+        scal = self._get("scal", (4,), torch.float32)
+        self._sync_in()
+        self.model.shard_forward_items(item_rows.data_ptr(), logits.data_ptr(), grad.data_ptr(), scal.data_ptr())
+        self._sync_out()
+        return grad, scal, logits
+
+    def reduce_users(self, item_rows):
+        """the user half: touches the fetched rows and the local user rows only - it may run beside the gradient exchange"""
+        self._sync_in()
+        self.model.shard_reduce_users(item_rows.data_ptr())
+        self._sync_out()
 
     def apply_items(self, req_recv, grad_recv):
         self._sync_in()
@@ -346,12 +372,27 @@ class ShardedSvd(object):
         t = self._phase("all_to_all rows")
         item_rows = c.all_to_all(rows_out)                                 # chunk w = the rows owner w holds for my slots
         self._end(t)
-        t = self._phase("forward_reduce")
-        grad, scal, logits = be.forward_reduce(item_rows)
-        self._end(t)
-        t = self._phase("all_to_all grads")
-        grad_recv = c.all_to_all(grad)                                     # by requester: rank order = fixed add order
-        self._end(t)
+        if hasattr(be, "forward_items"):
+            # the user half needs nothing the gradient exchange touches: it runs on the model's stream while RCCL moves the
+            # gradient rows on its own; the 16-byte all-reduce of the scalars goes out early as well
+            t = self._phase("forward_items")
+            grad, scal, logits = be.forward_items(item_rows)
+            self._end(t)
+            t = self._phase("all_to_all grads (start) + reduce_users")
+            grad_recv, work = c.all_to_all_start(grad, self._recv_buf(grad))   # by requester: rank order = fixed add order
+            be.reduce_users(item_rows)
+            self._end(t)
+            t = self._phase("all_to_all grads (wait)")
+            if work is not None:
+                work.wait()
+            self._end(t)
+        else:
+            t = self._phase("forward_reduce")
+            grad, scal, logits = be.forward_reduce(item_rows)
+            self._end(t)
+            t = self._phase("all_to_all grads")
+            grad_recv = c.all_to_all(grad)                                 # by requester: rank order = fixed add order
+            self._end(t)
         t = self._phase("apply_items")
         be.apply_items(req_recv, grad_recv)
         self._end(t)
@@ -360,6 +401,14 @@ class ShardedSvd(object):
         be.finish_step(scal)
         self._end(t)
         return logits, be.routed()["mine"], scal
+
+    def _recv_buf(self, like):
+        """a persistent receive buffer of the same shape (no allocation per step; an exchange in flight must not land in memory
+        the caching allocator may hand out again)"""
+        b = getattr(self, "_grad_recv", None)
+        if b is None or b.shape != like.shape or b.device != like.device or b.dtype != like.dtype:
+            b = self._grad_recv = torch.empty_like(like)
+        return b
 
     def wire_bytes_per_step(self, batch_global):
         """bytes this rank sends over xGMI per step (requests + rows + gradient rows to the world-1 peers)"""
