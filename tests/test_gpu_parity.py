@@ -205,21 +205,23 @@ def test_sort_large_random_matches_numpy(B):
 
 
 @pytest.mark.parametrize("n", [20_000, 300_000, 10_000_000, 20_000_000])
-def test_sort_one_launch_per_pass_edges(n):
-    """The batch-sized radix sort (k_rs2_first + one k_rs2_pass per 8-bit digit: tiles of 4096 keys, offsets derived from the
-    per-tile histogram matrix, the next pass's histogram counted by integer atomics) at its edges: 2, 3 and 4 passes, one key,
-    partial waves and tiles, exactly 128 tiles (its limit), one key more (falls back to the three-launch form), heavy duplicates."""
+def test_sort_one_workgroup_per_column_edges(n):
+    """The look-ahead form of the radix sort (k_psort: ONE launch, one 1024-thread workgroup per key column, all passes inside;
+    wave-private LDS counters, ballot ranks) at its edges: 2, 3 and 4 passes (15, 19, 24, 25 key bits), one key, partial rounds
+    and chunks, a hot id on a third of the batch and a block of equal keys - against np.argsort(kind="stable") and against the
+    nine-launch form."""
     rs = np.random.RandomState(n % 1000 + 3)
-    with T.SvdModel(n, 16, 4, optimizer="sgd") as m:                # 15, 19, 24 and 25 key bits
-        for B in (1, 63, 64, 4095, 4096, 4097, 100_000, 262_144, 524_288, 524_289):
+    with T.SvdModel(n, 16, 4, optimizer="sgd") as m:
+        for B in (1, 63, 64, 65, 1023, 1024, 1025, 4097, 100_000, 262_144, 300_001):
             ids = rs.randint(0, n, B).astype(np.int32)
-            if B > 1000:                                     # a hot id on a third of the batch + a block of equal keys
+            if B > 1000:
                 ids[rs.rand(B) < 0.33] = ids[0]
                 ids[B // 2: B // 2 + 500] = n - 1
-            ks, ps = m.sort_segments(0, ids)
             want = np.argsort(ids, kind="stable").astype(np.int32)
-            assert np.array_equal(ps, want), (n, B)
-            assert np.array_equal(ks, ids[want]), (n, B)
+            for side in (2, 0):
+                ks, ps = m.sort_segments(side, ids)
+                assert np.array_equal(ps, want), (n, B, side)
+                assert np.array_equal(ks, ids[want]), (n, B, side)
 
 
 # ------------------------------------------------------------------ determinism

@@ -202,7 +202,11 @@ def test_run_ahead_between_calls_is_invisible():
     sr = rs.randint(1, 6, N).astype(np.float32)
     N2 = 7777
     plan = [("steps", 1000, 3), ("steps", 1000, 5), ("steps", 1000, 1), ("steps", 700, 4), ("draw", 12345, 50), ("steps", 700, 9),
-            ("state",), ("steps", 700, 2), ("store", N2), ("steps", 256, 40), ("steps", 256, 40), ("steps", 256, 300)]
+            ("state",), ("steps", 700, 2), ("store", N2), ("steps", 256, 40), ("steps", 256, 40), ("steps", 256, 300),
+            # calls of >= 8 steps end by sorting the next call's first batch (drawn ahead) inside their last launch: the same
+            # call again takes that sort; a host-fed step, another batch size or a short call in between must not
+            ("steps", 1000, 20), ("steps", 1000, 20), ("fed", 500), ("steps", 1000, 20), ("steps", 1000, 8), ("steps", 1000, 8),
+            ("steps", 900, 8), ("steps", 1000, 3), ("steps", 1000, 12), ("state",), ("steps", 1000, 12)]
     out = []
     for device_draw in (False, True):
         with T.SvdModel(U, I, D, adam_mode="lazy", device=0) as m:
@@ -220,6 +224,10 @@ def test_run_ahead_between_calls_is_invisible():
                         log.append(m.train_steps_drawn(B, k, want_loss=True).tobytes())
                     else:
                         log.append(m.train_steps_resident(np.random.randint(0, n_store, (k, B)), B).tobytes())
+                elif op[0] == "fed":
+                    k0 = len(log) * 37 % (n_store - op[1])
+                    lg, loss, _ = m.train_step(su[k0:k0 + op[1]], si[k0:k0 + op[1]], sr[k0:k0 + op[1]])
+                    log.append(lg.tobytes())
                 elif op[0] == "draw":
                     log.append((m.draw_ids(op[1], op[2]) if device_draw else np.random.randint(0, op[1], op[2])).tobytes())
                 elif op[0] == "state":

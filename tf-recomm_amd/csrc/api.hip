@@ -65,7 +65,7 @@ struct tfr_model {
     // two-table form of the fused big-table step (RedArgs::sel): the alternate item table, the per-row "which table" word,
     // the per-entry {partner row | old table} words of the current batch; q_dirty = some row may live in q_alt
     float* q_alt = nullptr; int32_t* q_sel = nullptr; int32_t* osel = nullptr; bool q_dirty = false;
-    int32_t* rs2_hist = nullptr;      // rsort2: [RS2_MAX_PASSES][2][256 * RS2_MAX_TILES] per-tile digit histograms
+    bool sort_persistent = false;     // radix sorts take the one-workgroup-per-column form (k_psort): set around look-ahead sorts
     bool csort_ok = false;
     float *gq = nullptr, *gp = nullptr, *gbq = nullptr, *gbp = nullptr;
     int32_t *map_u = nullptr, *map_i = nullptr;
@@ -198,7 +198,6 @@ static void free_workspace(tfr_model* m) {
     dfree(m->partials); dfree(m->lrank_u); dfree(m->lrank_i); dfree(m->hist_u); dfree(m->hist_i);
     dfree(m->offs_u); dfree(m->offs_i); dfree(m->binbase_u); dfree(m->binbase_i);
     dfree(m->blocktot_u); dfree(m->blocktot_i);
-    dfree(m->rs2_hist); m->rs2_hist = nullptr;
     dfree(m->osel); m->osel = nullptr;
     for (int pz = 0; pz < 2; ++pz) for (int sd = 0; sd < 2; ++sd) { dfree(m->srt[pz][sd]); m->srt[pz][sd] = nullptr; }
     dfree(m->d_in); m->d_in = nullptr;
@@ -720,28 +719,24 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
     const int passes = (maxbits + 7) / 8;
     int32_t* tmpk[2] = {m->ks2_u, m->ks2_i};
     int32_t* tmpv[2] = {m->ps2_u, m->ps2_i};
-    static int use_rs2 = -1;                             // TFR_RSORT2=0: the three-launches-per-pass form, kept for A/B
-    if (use_rs2 < 0) { const char* e = getenv("TFR_RSORT2"); use_rs2 = (e && e[0] == '0') ? 0 : 1; }
-    if (use_rs2 && rsort2_eligible(B) && passes <= RS2_MAX_PASSES) {
-        int rc;
-        if (!m->rs2_hist && (rc = dmalloc(&m->rs2_hist, (size_t)RS2_MAX_PASSES * 2 * 256 * RS2_MAX_TILES))) return rc;
-        RSort2Args a;
+    if (m->sort_persistent && passes <= 4) {
+        // one launch, one workgroup per column (sort.hip k_psort): slow to finish (~0.1 ms), next to nothing taken from the
+        // kernels it runs beside - the look-ahead sort of the big-table step
+        PSortArgs a;
         memset(&a, 0, sizeof(a));
-        a.B = B; a.passes = passes; a.ntiles = (int32_t)((B + 4095) / 4096);
+        a.B = B; a.passes = passes;
         for (int c = 0; c < ncols; ++c) {
             a.keys_in[c] = keys[c];
             a.keys_fin[c] = ks_out[c]; a.vals_fin[c] = ps_out[c];
             a.keys_tmp[c] = tmpk[c]; a.vals_tmp[c] = tmpv[c];
             a.limit[c] = limits ? (int32_t)limits[c] : 0x7fffffff;
-            for (int p = 0; p < RS2_MAX_PASSES; ++p) a.hist[p][c] = m->rs2_hist + ((size_t)p * 2 + c) * 256 * RS2_MAX_TILES;
         }
-        a.err = limits ? m->d_err : nullptr;             // ids outside the tables void the step
-        if (store_ids) {                                 // the first launch gathers the batch from the resident store itself
+        a.err = (limits || store_ids) ? m->d_err : nullptr;      // ids outside the tables void the step
+        if (store_ids) {                                         // pass 0 gathers the batch from the resident store itself
             a.ids = store_ids; a.store = m->store; a.N = m->N;
             a.u_out = m->d_u; a.i_out = m->d_i; a.r_out = m->d_r;
-            a.err = m->d_err;
         }
-        launch_rsort2(a, ncols, m->stream);
+        launch_psort(a, ncols, m->stream);
         HIPCHK(hipGetLastError());
         return TFR_OK;
     }
@@ -825,6 +820,7 @@ static bool tiles_eligible(const tfr_model* m, int64_t B) {
 static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, const float*& dr, int64_t B,
                           float* d_logits, const int64_t* d_store_ids, FinArgs& f, int& nblk, bool& fin_done,
                           bool tiles = false, bool sort_only = false) {
+    m->pf_valid = false;                                 // the sort scratch doubles as the published tables of the tile step
     const tfr_opts& o = m->o;
     hipStream_t s = m->stream;
     int rc;
@@ -1690,10 +1686,15 @@ static uint32_t mask_for(uint32_t rng) {
 // own launches (feed): the host never spends a stretch feeding the draw stream while the main stream sits empty (a 20-step
 // call: the first step used to start 36 us into the call, behind six draw launches).
 // need(step, stream) makes `stream` wait for the chunk that holds that step's ids.  NULL = ids staged by the host.
+static int enqueue_run_ahead(tfr_model* m, int64_t B, int64_t nsteps, uint32_t rng);
+
 struct IdsReady {
     tfr_model* m = nullptr;
     int64_t B = 0, nsteps = 0;
     uint32_t rng = 0;
+    // tail: the call's last small-table step also sorts the NEXT call's first batch (its ids are drawn ahead into the alternate
+    // buffer as soon as this call's own chunks are out), so that call starts from a published sort like every later step
+    bool tail = false, ahead_done = false;
     std::vector<int64_t> first;                            // first[c] = first step of chunk c; first[nchunks] = nsteps
     int enq = 0;                                           // chunks enqueued so far
     int waited[2] = {-1, -1};                              // highest chunk waited for: [0] main stream, [1] stream2
@@ -1743,7 +1744,28 @@ struct IdsReady {
     // after a step's launches: one more chunk for the draw stream (never before them - with ids drawn ahead by the previous
     // call the first step must not queue behind draw launches it does not need; one per step keeps the host ahead of a
     // 20-us step and the generator busy from the start, so the run-ahead draw at the end of the call fits inside it)
-    int feed(int64_t step) { return enqueue_through(step, 1); }
+    int feed(int64_t step) {
+        int rc = enqueue_through(step, 1);
+        if (!rc && tail && !ahead_done && enq >= (int)first.size() - 1) rc = run_ahead();
+        return rc;
+    }
+    int run_ahead() {
+        if (ahead_done) return TFR_OK;
+        ahead_done = true;
+        return enqueue_run_ahead(m, B, nsteps, rng);
+    }
+    // ids of the step after this call's last one (device pointer), ready on `st`; NULL when there is no run-ahead
+    int tail_ids(hipStream_t st, const int64_t** out) {
+        *out = nullptr;
+        if (!tail) return TFR_OK;
+        int rc = enqueue_through(nsteps);
+        if (!rc) rc = run_ahead();
+        if (rc) return rc;
+        if (!m->spec_valid) return TFR_OK;
+        if (hipStreamWaitEvent(st, m->spec_ev, 0) != hipSuccess) return fail(TFR_ERR_HIP, "hipStreamWaitEvent failed");
+        *out = m->d_ids_alt;
+        return TFR_OK;
+    }
     int need(int64_t step, hipStream_t st, int which) {
         if (step >= nsteps) step = nsteps - 1;
         int rc = enqueue_through(step);
@@ -1778,6 +1800,9 @@ static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, i
     // TFR_SORT_LATE=0: start it beside the item-side kernel (the round-1 order), kept for A/B
     static int late = -1;
     if (late < 0) { const char* e = getenv("TFR_SORT_LATE"); late = (e && e[0] == '0') ? 0 : 1; }
+    static int psort_env = -1;                             // TFR_PSORT=0: the look-ahead sort as nine launches again (A/B)
+    if (psort_env < 0) { const char* e = getenv("TFR_PSORT"); psort_env = (e && e[0] == '0') ? 0 : 1; }
+    const bool psort_on = psort_env == 1;
     if (late) {
         m->ev_mid_on = true;
         for (int32_t s = 0; s < nsteps && !rc; ++s) {
@@ -1790,9 +1815,14 @@ static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, i
             if (ready && (rc = ready->feed(first_step + s))) break;
             if (s + 1 < nsteps) {
                 swap_sortset(m);                           // the next step's set: free since step s-1, which the main stream has passed
-                HIPCHK(hipStreamWaitEvent(m->stream2, m->ev_mid, 0));
+                // the one-workgroup sort needs most of a step to finish and disturbs nothing: it starts as soon as its buffer
+                // set is free (step s-1 done), beside the item-side kernel; the nine-launch form starts after that kernel
+                if (psort_on) HIPCHK(hipStreamWaitEvent(m->stream2, s == 0 ? m->ev_first : m->ev_free[z ^ 1], 0));
+                else HIPCHK(hipStreamWaitEvent(m->stream2, m->ev_mid, 0));
                 m->stream = m->stream2;
+                m->sort_persistent = psort_on;
                 rc = sort_batch(s + 1);
+                m->sort_persistent = false;
                 m->stream = main_s;
                 if (!rc) rc = hipEventRecord(m->ev_sorted[z ^ 1], m->stream2) == hipSuccess ? TFR_OK : fail(TFR_ERR_HIP, "event record");
             }
@@ -1842,12 +1872,13 @@ static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nst
     } else {
     for (int32_t s = 0; s < nsteps; ++s) {
         if (ready && (rc = ready->need(first_step + s + ((first_step + s + 2) * B <= m->n_ids ? 1 : 0), m->stream, 0))) return rc;
+        // look ahead past the end of this call too when more staged batches follow: the
+        // next call then starts presorted (the sort is free, hidden in this launch)
+        const int64_t* nxt = (first_step + s + 2) * B <= m->n_ids ? m->d_ids + (first_step + s + 1) * B : nullptr;
+        if (!nxt && ready && s == nsteps - 1 && (rc = ready->tail_ids(m->stream, &nxt))) return rc;     // drawn call: the next call's first batch
         if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr,
                                  loss_out ? m->step_out + (size_t)s * 4 : nullptr,
-                                 m->d_ids + (first_step + s) * B,
-                                 // look ahead past the end of this call too when more staged batches follow: the
-                                 // next call then starts presorted (the sort is free, hidden in this launch)
-                                 (first_step + s + 2) * B <= m->n_ids ? m->d_ids + (first_step + s + 1) * B : nullptr))) {
+                                 m->d_ids + (first_step + s) * B, nxt))) {
             m->pf_valid = false;
             return rc;
         }
@@ -2028,6 +2059,34 @@ int tfr_join_draws(tfr_model* m) {
     return TFR_OK;
 }
 
+// run ahead: the next call's first batches, drawn into the other id buffer (last read by the call before the current one)
+static int enqueue_run_ahead(tfr_model* m, int64_t B, int64_t nsteps, uint32_t rng) {
+    int rc;
+    if (rng != 0) {
+        int64_t spec = 131072 / B;
+        if (spec > 8) spec = 8;
+        if (spec > nsteps) spec = nsteps;
+        if (spec < 1) spec = 1;
+        if (spec * B > m->d_ids_alt_cap || m->d_ids_alt_cap < m->d_ids_cap) {   // keep both buffers the same size: a repeat of this call then fits
+            HIPCHK(hipStreamSynchronize(m->stream));       // the old alternate buffer may still be read by queued steps
+            HIPCHK(hipStreamSynchronize(m->stream3));
+            dfree(m->d_ids_alt);
+            m->d_ids_alt = nullptr; m->d_ids_alt_cap = 0;
+            int64_t want = spec * B > m->d_ids_cap ? spec * B : m->d_ids_cap;
+            if (want < IDS_MIN_CAP) want = IDS_MIN_CAP;
+            if ((rc = dmalloc(&m->d_ids_alt, (size_t)want))) return rc;
+            m->d_ids_alt_cap = want;
+        }
+        HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));  // the alternate buffer's last readers (before this call) are done
+        HIPCHK(hipMemcpyAsync(m->d_rng_snap, m->d_rng, 625 * 4, hipMemcpyDeviceToDevice, m->stream3));
+        launch_mt_draw(m->d_rng, m->d_ids_alt, spec * B, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(m->spec_ev, m->stream3));
+        m->spec_valid = true; m->spec_B = B; m->spec_N = m->N; m->spec_steps = spec;
+    }
+    return TFR_OK;
+}
+
 int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_out) {
     MODEL_ENTER(m);
     if (!m->N) return fail(TFR_ERR_STATE, "no resident triples: call tfr_upload_triples first");
@@ -2065,39 +2124,24 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
         HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));
         HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));
     }
-    m->pf_valid = false;                                   // the buffer's contents change: no published look-ahead sort survives
+    // a published look-ahead sort survives only if it is the sort of this call's first batch (the previous call's last step made
+    // it from the ids drawn ahead, now at the head of d_ids); anything else in the buffer changes
+    if (!(pre && m->pf_valid && m->pf_ids == m->d_ids && m->pf_B == B)) m->pf_valid = false;
     m->n_ids = total;
     IdsReady ready;
     ready.m = m; ready.B = B; ready.nsteps = nsteps; ready.rng = rng;
+    {
+        static int tail_on = -1;                           // TFR_TAIL_SORT=0: A/B switch
+        if (tail_on < 0) { const char* e = getenv("TFR_TAIL_SORT"); tail_on = (e && e[0] == '0') ? 0 : 1; }
+        ready.tail = tail_on && rng != 0 && nsteps >= 8 && tiles_eligible(m, B) && !m->prof;
+    }
     ready.plan(B >= 65536 ? 1 : (65536 / B < 16 ? 65536 / B : 16), pre);     // a chunk holds at most ~64K ids / 16 steps
     if (rng == 0) HIPCHK(hipMemsetAsync(m->d_ids, 0, (size_t)total * 8, m->stream3));   // one-rating store: no draw consumed
     tr.mark(pre ? "ids drawn ahead taken" : "no ids drawn ahead");
     if ((rc = staged_steps(m, 0, B, nsteps, loss_out, &ready))) return rc;
     tr.mark("all steps enqueued");
     if ((rc = ready.enqueue_through(nsteps))) return rc;   // (every chunk is out by now; this is a no-op kept for clarity)
-    // run ahead: the next call's first batches, into the other buffer (last read by the call before this one)
-    if (rng != 0) {
-        int64_t spec = 131072 / B;
-        if (spec > 8) spec = 8;
-        if (spec > nsteps) spec = nsteps;
-        if (spec < 1) spec = 1;
-        if (spec * B > m->d_ids_alt_cap || m->d_ids_alt_cap < m->d_ids_cap) {   // keep both buffers the same size: a repeat of this call then fits
-            HIPCHK(hipStreamSynchronize(m->stream));       // the old alternate buffer may still be read by queued steps
-            HIPCHK(hipStreamSynchronize(m->stream3));
-            dfree(m->d_ids_alt);
-            m->d_ids_alt = nullptr; m->d_ids_alt_cap = 0;
-            int64_t want = spec * B > m->d_ids_cap ? spec * B : m->d_ids_cap;
-            if (want < IDS_MIN_CAP) want = IDS_MIN_CAP;
-            if ((rc = dmalloc(&m->d_ids_alt, (size_t)want))) return rc;
-            m->d_ids_alt_cap = want;
-        }
-        HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));  // the alternate buffer's last readers (before this call) are done
-        HIPCHK(hipMemcpyAsync(m->d_rng_snap, m->d_rng, 625 * 4, hipMemcpyDeviceToDevice, m->stream3));
-        launch_mt_draw(m->d_rng, m->d_ids_alt, spec * B, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(m->spec_ev, m->stream3));
-        m->spec_valid = true; m->spec_B = B; m->spec_N = m->N; m->spec_steps = spec;
-    }
+    if (rng != 0 && (rc = ready.run_ahead())) return rc;  // (the tail sort has usually issued it already)
     tr.mark("run-ahead draw enqueued");
     return TFR_OK;
 }
@@ -2122,7 +2166,7 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
                  tile_step_epg((int)ntiles, G, V), G, V, nt);
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
-        snprintf(tmp, sizeof(tmp), "sort=k_rs2_first (gathers the batch) + k_rs2_pass x%d;reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
+        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch; look-ahead batches: one k_psort launch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
                  "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
                  ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
     } else if (csort) {
@@ -2225,14 +2269,19 @@ int tfr_forward_resident(tfr_model* m, int64_t lo, int64_t hi, float* logits_out
 
 int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t B, int32_t* ks_out, int32_t* ps_out) {
     MODEL_ENTER(m);
-    if (side != 0 && side != 1) return fail(TFR_ERR_ARG, "side must be 0 (user) or 1 (item)");
+    if (side < 0 || side > 3) return fail(TFR_ERR_ARG, "side must be 0 (user) or 1 (item), + 2 for the one-launch form of the radix sort");
+    const bool persistent = (side & 2) != 0;
+    side &= 1;
     if (B < 0 || (B > 0 && (!ids || !ks_out || !ps_out))) return fail(TFR_ERR_ARG, "bad batch / null pointer");
     if (B == 0) return TFR_OK;
     int rc;
     if ((rc = ensure_capacity(m, B))) return rc;
     HIPCHK(hipMemcpyAsync(m->d_u, ids, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->d_i, ids, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
-    if ((rc = sort_columns(m, m->d_u, m->d_i, B))) return rc;      // the training step's own sort path
+    m->sort_persistent = persistent;
+    rc = sort_columns(m, m->d_u, m->d_i, B);                       // the training step's own sort path
+    m->sort_persistent = false;
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ks_out, side == 0 ? m->ks_u : m->ks_i, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(ps_out, side == 0 ? m->ps_u : m->ps_i, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));

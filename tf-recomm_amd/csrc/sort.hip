@@ -298,165 +298,116 @@ void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
-// rsort2: the same LSD radix sort for batches of up to RS2_MAX_TILES x 4096 keys (every training batch), in
-// 1 + passes launches instead of 3 x passes.  A block owns a tile of 4096 keys (4 per thread).
-//   k_rs2_first : (optional fused gather from the resident store +) range check + the per-tile histogram of digit 0;
-//                 zeroes the histograms of the later passes.
-//   k_rs2_pass  : reads the whole per-tile histogram matrix of its digit ([256][ntiles], <= 128 KB, L2-resident) and
-//                 derives its own global offsets from it (bin totals, bins before, tiles before - no scan launch);
-//                 ranks its keys (per-wave LDS counters: a wave owns 256 contiguous keys, four rounds of ballots, no
-//                 barrier between the rounds; one cross-wave prefix per digit); scatters key + value; and counts the
-//                 NEXT pass's per-tile histogram with integer atomics (destination tile, next digit) - integer adds,
-//                 so the counts do not depend on the order they arrive in.
-// Stable pass by pass (tiles before, then position inside the tile), so bit-exact against np.argsort(kind="stable").
-constexpr int RS2_TILE = 4096;
-constexpr int RS2_KPT = 4;                               // keys per thread
-
-__global__ __launch_bounds__(1024) void k_rs2_first(RSort2Args a) {
-    __shared__ int32_t cnt[256];
-    const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+// psort: the same LSD radix sort as ONE launch of ONE 1024-thread workgroup per key column - for the look-ahead sort of the
+// big-table step, which has a whole step (~0.45 ms) to finish in but must not take CUs from the bandwidth-bound kernels it runs
+// beside.  (Measured, A/B in one gpurun call: the nine-launch form costs the step its full 70 us even "hidden" on a second
+// stream - its 512-block launches take block slots from the fused kernels for as long as they wait on memory beside them; a
+// one-launch-per-pass form that counted the next pass's histogram with global atomics was slower still: device-scope atomics
+// cost ~35 us per 0.5 M on this part.)  No inter-workgroup communication at all: a column is one workgroup's business.
+//   per pass: (A) every wave counts the digits of its contiguous chunk (LDS adds on wave-private counters; pass 0 gathers the
+//   batch from the resident store here and writes the id / rate columns), (B) prefix over waves and digits, (C) every wave
+//   walks its chunk again 64 keys at a time - eight ballots give each key its rank among the equal digits of the round, the
+//   lowest lane of a digit group advances the wave's running offset - and scatters key + position.
+// Stable by construction (wave chunks in order, rounds in order, lanes in order): bit-exact against np.argsort(kind="stable").
+__global__ __launch_bounds__(1024) void k_psort(PSortArgs a) {
+    __shared__ int32_t wcnt[16][256];
+    __shared__ int32_t dtot[256];
+    __shared__ int32_t wsum[4];
+    const int col = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    if (tid < 256) {
-        cnt[tid] = 0;
-        for (int p = 1; p < a.passes; ++p) a.hist[p][col][(size_t)tid * a.ntiles + tile] = 0;
-    }
-    __syncthreads();
+    const int64_t B = a.B;
+    const int64_t chunk = ((B + 16 * 64 - 1) / (16 * 64)) * 64;          // keys per wave, a multiple of 64
+    const int64_t k0 = (int64_t)wave * chunk;
+    const int64_t k1 = (k0 + chunk < B) ? k0 + chunk : B;
     bool bad = false;
-#pragma unroll
-    for (int r = 0; r < RS2_KPT; ++r) {
-        const int64_t k = (int64_t)tile * RS2_TILE + wave * 256 + r * 64 + lane;
-        if (k >= a.B) continue;
-        int32_t key;
-        if (a.ids) {                                     // fused gather: dataio.py:115-117 on the resident store
-            int64_t id = a.ids[k];
-            if ((uint64_t)id >= (uint64_t)a.N) { if (a.err) atomicOr(a.err, 2); id = 0; }
-            const int4 rec = a.store[id];
-            key = col == 0 ? rec.x : rec.y;
-            if (col == 0) { a.u_out[k] = rec.x; a.i_out[k] = rec.y; a.r_out[k] = __int_as_float(rec.z); }
-        } else {
-            key = a.keys_in[col][k];
+    for (int pass = 0; pass < a.passes; ++pass) {
+        const int shift = 8 * pass;
+        const bool to_fin = ((a.passes - 1 - pass) & 1) == 0;              // ping-pong so that the last pass lands in the final buffers
+        const int32_t* __restrict__ kin = pass == 0 ? a.keys_in[col] : (to_fin ? a.keys_tmp[col] : a.keys_fin[col]);
+        const int32_t* __restrict__ vin = pass == 0 ? nullptr : (to_fin ? a.vals_tmp[col] : a.vals_fin[col]);
+        int32_t* __restrict__ kout = to_fin ? a.keys_fin[col] : a.keys_tmp[col];
+        int32_t* __restrict__ vout = to_fin ? a.vals_fin[col] : a.vals_tmp[col];
+        for (int q = tid; q < 16 * 256; q += 1024) (&wcnt[0][0])[q] = 0;
+        __syncthreads();
+        // (A) count
+        for (int64_t k = k0 + lane; k < k1; k += 64) {
+            int32_t key;
+            if (pass == 0 && a.ids) {                                      // fused gather: dataio.py:115-117 on the resident store
+                int64_t id = a.ids[k];
+                if ((uint64_t)id >= (uint64_t)a.N) { atomicOr(a.err, 2); id = 0; }
+                const int4 rec = a.store[id];
+                key = col == 0 ? rec.x : rec.y;
+                if (col == 0) { a.u_out[k] = rec.x; a.r_out[k] = __int_as_float(rec.z); }
+                else a.i_out[k] = rec.y;
+            } else {
+                key = kin[k];
+            }
+            if (pass == 0) bad |= (uint32_t)key >= (uint32_t)a.limit[col];
+            atomicAdd(&wcnt[wave][(key >> shift) & 255], 1);
         }
-        bad |= (uint32_t)key >= (uint32_t)a.limit[col];
-        atomicAdd(&cnt[key & 255], 1);
+        __syncthreads();
+        if (pass == 0 && a.ids) kin = col == 0 ? a.u_out : a.i_out;       // (C) re-reads the column (A) has just written
+        // (B) exclusive prefix: over the waves per digit, then over the digits
+        if (tid < 256) {
+            int32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const int32_t c = wcnt[w][tid];
+                wcnt[w][tid] = run;
+                run += c;
+            }
+            int32_t incl = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int32_t t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            dtot[tid] = incl - run;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            int32_t base = dtot[tid];
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+            dtot[tid] = base;
+        }
+        __syncthreads();
+        for (int q = tid; q < 16 * 256; q += 1024) (&wcnt[0][0])[q] += dtot[q & 255];
+        __syncthreads();
+        // (C) rank + scatter, 64 keys of the wave's chunk per round, in order
+        for (int64_t kb = k0; kb < k1; kb += 64) {
+            const int64_t k = kb + lane;
+            const bool valid = k < k1;
+            const int32_t key = valid ? kin[k] : 0;
+            const int32_t val = valid ? (vin ? vin[k] : (int32_t)k) : 0;
+            const int32_t digit = (key >> shift) & 255;
+            unsigned long long mask = __ballot(valid);
+#pragma unroll
+            for (int bit = 1; bit < 256; bit <<= 1) {
+                const unsigned long long mb = __ballot((digit & bit) != 0);
+                mask &= (digit & bit) ? mb : ~mb;
+            }
+            const unsigned long long below = mask & ((1ull << lane) - 1ull);
+            int32_t base = 0;
+            if (valid && below == 0) {                                     // one lane per digit group moves the wave's offset on
+                base = wcnt[wave][digit];
+                wcnt[wave][digit] = base + __popcll(mask);
+            }
+            const int leader = valid ? __ffsll((long long)mask) - 1 : lane;
+            base = __shfl(base, leader, 64);
+            if (valid) {
+                const int32_t dst = base + __popcll(below);
+                kout[dst] = key;
+                vout[dst] = val;
+            }
+        }
+        __syncthreads();                                                   // the next pass reads what this one wrote (same CU)
     }
     if (a.err && __any(bad) && lane == 0) atomicOr(a.err, 1);
-    __syncthreads();
-    if (tid < 256) a.hist[0][col][(size_t)tid * a.ntiles + tile] = cnt[tid];
 }
 
-__global__ __launch_bounds__(1024) void k_rs2_pass(RSort2Args a, int pass) {
-    __shared__ int32_t part_tot[4][256], part_bef[4][256];
-    __shared__ int32_t gbase[256];
-    __shared__ int32_t wcnt[16][256];
-    __shared__ int32_t wsum[4];
-    const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int shift = 8 * pass;
-    const bool last = pass + 1 >= a.passes;
-    // ping-pong so that the last pass lands in the final buffers; pass p reads what pass p-1 wrote
-    auto to_fin = [&](int p) { return ((a.passes - 1 - p) & 1) == 0; };
-    const int32_t* __restrict__ kin;
-    const int32_t* __restrict__ vin = nullptr;
-    if (pass == 0) kin = a.ids ? (col == 0 ? a.u_out : a.i_out) : a.keys_in[col];      // fused gather: the columns k_rs2_first wrote
-    else { kin = to_fin(pass - 1) ? a.keys_fin[col] : a.keys_tmp[col]; vin = to_fin(pass - 1) ? a.vals_fin[col] : a.vals_tmp[col]; }
-    int32_t* __restrict__ kout = to_fin(pass) ? a.keys_fin[col] : a.keys_tmp[col];
-    int32_t* __restrict__ vout = to_fin(pass) ? a.vals_fin[col] : a.vals_tmp[col];
-    // keys of this thread (issued first: the longest latency of the block)
-    int32_t key[RS2_KPT], val[RS2_KPT];
-    bool valid[RS2_KPT];
-#pragma unroll
-    for (int r = 0; r < RS2_KPT; ++r) {
-        const int64_t k = (int64_t)tile * RS2_TILE + wave * 256 + r * 64 + lane;
-        valid[r] = k < a.B;
-        key[r] = valid[r] ? kin[k] : 0;
-        val[r] = valid[r] ? (vin ? vin[k] : (int32_t)k) : 0;
-    }
-    for (int q = tid; q < 16 * 256; q += 1024) (&wcnt[0][0])[q] = 0;
-    // phase A: this digit's histogram matrix -> entries of smaller bins + entries of my bin in earlier tiles
-    {
-        const int d = tid & 255, q = tid >> 8;
-        const int per = (a.ntiles + 3) >> 2;
-        const int t0 = q * per, t1 = (t0 + per < a.ntiles) ? t0 + per : a.ntiles;
-        const int32_t* __restrict__ h = a.hist[pass][col] + (size_t)d * a.ntiles;
-        int32_t tot = 0, bef = 0;
-        for (int t = t0; t < t1; ++t) {
-            const int32_t c = h[t];
-            tot += c;
-            bef += (t < tile) ? c : 0;
-        }
-        part_tot[q][d] = tot;
-        part_bef[q][d] = bef;
-    }
-    __syncthreads();
-    if (tid < 256) {
-        const int32_t tot = (part_tot[0][tid] + part_tot[1][tid]) + (part_tot[2][tid] + part_tot[3][tid]);
-        const int32_t bef = (part_bef[0][tid] + part_bef[1][tid]) + (part_bef[2][tid] + part_bef[3][tid]);
-        int32_t incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int32_t t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        part_tot[0][tid] = incl - tot;                    // exclusive inside the wave
-        part_bef[0][tid] = bef;
-    }
-    __syncthreads();
-    if (tid < 256) {
-        int32_t base = part_tot[0][tid];
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        gbase[tid] = base + part_bef[0][tid];
-    }
-    // phase B: ranks inside the tile.  A wave owns keys [wave * 256, wave * 256 + 256) in round-major order.
-    int32_t lrank[RS2_KPT];
-#pragma unroll
-    for (int r = 0; r < RS2_KPT; ++r) {
-        const int32_t digit = (key[r] >> shift) & 255;
-        unsigned long long mask = __ballot(valid[r]);
-#pragma unroll
-        for (int bit = 1; bit < 256; bit <<= 1) {
-            const unsigned long long mb = __ballot((digit & bit) != 0);
-            mask &= (digit & bit) ? mb : ~mb;
-        }
-        const unsigned long long below = mask & ((1ull << lane) - 1ull);
-        int32_t base = 0;
-        if (valid[r] && below == 0) {                     // the lowest lane of each digit group bumps the wave's counter
-            base = wcnt[wave][digit];
-            wcnt[wave][digit] = base + __popcll(mask);
-        }
-        const int leader = valid[r] ? __ffsll((long long)mask) - 1 : lane;
-        base = __shfl(base, leader, 64);
-        lrank[r] = base + __popcll(below);
-    }
-    __syncthreads();
-    if (tid < 256) {                                      // exclusive prefix over the 16 waves, per digit
-        int32_t run = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int32_t c = wcnt[w][tid];
-            wcnt[w][tid] = run;
-            run += c;
-        }
-    }
-    __syncthreads();
-    int32_t* __restrict__ hn = last ? nullptr : a.hist[pass + 1][col];
-#pragma unroll
-    for (int r = 0; r < RS2_KPT; ++r) {
-        if (!valid[r]) continue;
-        const int32_t digit = (key[r] >> shift) & 255;
-        const int32_t dst = gbase[digit] + wcnt[wave][digit] + lrank[r];
-        kout[dst] = key[r];
-        vout[dst] = val[r];
-        if (hn) atomicAdd(&hn[(size_t)((key[r] >> (shift + 8)) & 255) * a.ntiles + dst / RS2_TILE], 1);
-    }
-}
-
-bool rsort2_eligible(int64_t B) { return B >= 1 && (B + RS2_TILE - 1) / RS2_TILE <= RS2_MAX_TILES; }
-
-void launch_rsort2(const RSort2Args& a, int ncols, hipStream_t s) {
-    const dim3 grid(a.ntiles, ncols);
-    hipLaunchKernelGGL(k_rs2_first, grid, dim3(1024), 0, s, a);
-    for (int p = 0; p < a.passes; ++p) hipLaunchKernelGGL(k_rs2_pass, grid, dim3(1024), 0, s, a, p);
+void launch_psort(const PSortArgs& a, int ncols, hipStream_t s) {
+    hipLaunchKernelGGL(k_psort, dim3(ncols), dim3(1024), 0, s, a);
 }
 
 }  // namespace tfr

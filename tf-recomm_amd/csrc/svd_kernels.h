@@ -304,20 +304,16 @@ struct RSortArgs {
 };
 void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s);
 
-// rsort2 (sort.hip): the radix sort of a training batch in 1 + passes launches; tiles of 4096 keys, at most RS2_MAX_TILES
-constexpr int RS2_MAX_TILES = 128;
-constexpr int RS2_MAX_PASSES = 4;
-struct RSort2Args {
+// psort (sort.hip): the radix sort as one launch of one workgroup per key column (look-ahead sort of the big-table step)
+struct PSortArgs {
     const int32_t* keys_in[2];                               // pass 0 input (unless ids != NULL)
     int32_t* keys_fin[2]; int32_t* vals_fin[2];              // where the sorted keys / positions must end up
     int32_t* keys_tmp[2]; int32_t* vals_tmp[2];              // ping-pong partner
-    int32_t* hist[RS2_MAX_PASSES][2];                        // [256 * ntiles] per pass and column, bin-major
-    int32_t passes, ntiles;
+    int32_t passes;
     int64_t B;
-    int32_t limit[2]; int32_t* err;                          // err != NULL: keys outside [0, limit) flag |= 1
+    int32_t limit[2]; int32_t* err;                          // keys outside [0, limit) flag |= 1 (err may be NULL without ids)
     const int64_t* ids; const int4* store; int64_t N; float* r_out; int32_t* u_out; int32_t* i_out;   // fused gather (pass 0)
 };
-bool rsort2_eligible(int64_t B);
-void launch_rsort2(const RSort2Args& a, int ncols, hipStream_t s);
+void launch_psort(const PSortArgs& a, int ncols, hipStream_t s);
 
 }  // namespace tfr
