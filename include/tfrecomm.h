@@ -248,6 +248,15 @@ int tfr_shard_forward_reduce(tfr_model* m, const float* d_item_rows /* [world * 
 int tfr_shard_forward_items(tfr_model* m, const float* d_item_rows, float* d_logits, float* d_item_grad, float* d_scalars4);
 int tfr_shard_reduce_users(tfr_model* m, const float* d_item_rows);
 int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* d_grad_recv, int64_t n);
+/* Preparing batch s+1 while step s runs.  The model keeps TWO routed-batch sets; tfr_shard_select says which one the route_* calls
+ * fill and the forward / reduce / apply calls consume.  tfr_shard_presort does the index work of a step ahead of time on the
+ * selected set (it depends on the routed batch and on the requests received, never on a table): the routed samples sorted by
+ * local user row and by request slot and - with d_req_recv [n], the requests this rank received as an owner - those requests
+ * padded and sorted by item row; the step calls then skip their own sorts.  A caller puts bucket -> exchange -> route_recs ->
+ * exchange -> presort of batch s+1 on a side stream (tfr_set_stream) beside step s; every buffer these calls write belongs to
+ * the selected set or to the sort scratch, which the step calls then do not touch. */
+int tfr_shard_select(tfr_model* m, int32_t which /* 0 or 1 */);
+int tfr_shard_presort(tfr_model* m, const int32_t* d_req_recv /* may be NULL */, int64_t n);
 int tfr_shard_finish_step(tfr_model* m, const float* d_scalars4 /* global sums */);
 
 /* ---- data-parallel building blocks (replicated tables, small enough that every GPU holds

@@ -189,6 +189,62 @@ def test_capacity_overflow_voids_the_step_loudly():
     hip.model.close()
 
 
+def _pipelined_worker(rank, world, port, kw, U, I, D, B, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfrecomm_amd import sharded, _lib as L
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        rs = np.random.RandomState(21)
+        t = rand_tables(rs, U, I, D)
+        Ns = 4 * B + 7
+        su, si = dup_heavy_ids(rs, U, Ns), dup_heavy_ids(rs, I, Ns)
+        sr = rs.randint(1, 6, Ns).astype(np.float32)
+        keep = [torch.from_numpy(x).to(dev) for x in (su, si, sr)]
+        rs_own = np.random.RandomState(700 + rank)
+        batches = [rs_own.randint(0, Ns, B) for _ in range(steps)]
+        d_batches = [torch.from_numpy(b).to(dev) for b in batches]
+        tables = {}
+        for mode in ("pipelined", "plain"):
+            ref = make_oracle(U, I, D, t, **kw)
+            comm = sharded.Comm()
+            m = sharded.ShardedSvd(U, I, D, comm, lambda ur, ir, d: sharded.HipShard(ur, ir, d, 0, **kw), device=dev)
+            m.set_tables_from_global(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+            m.backend.set_store(*keep)
+            for s in range(steps):
+                nxt = d_batches[s + 1] if (mode == "pipelined" and s + 1 < steps and s != 2) else None   # step 3 starts without a prepared batch
+                logits, mine, scal = m.train_step_local_ids(d_batches[s], nxt)
+                torch.cuda.synchronize()
+                allids = [None] * world
+                dist.all_gather_object(allids, batches[s])
+                union = np.concatenate(allids)
+                wl, wloss, wreg = ref.train_step(su[union], si[union], sr[union])
+                sc = scal.cpu().numpy()
+                tol = RTOL * (s + 1)
+                assert abs(sc[0] - wloss) <= tol * abs(wloss) and abs(sc[1] - wreg) <= tol * abs(wreg), (mode, s)
+            m.backend.sync()
+            got = m.gather_global_tables()
+            for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+                assert rel_err(got[tid], ref.tables()[tid]) <= (2e-4 if kw.get("optimizer") == "adam" else RTOL * steps), "table %d (%s)" % (tid, mode)
+            tables[mode] = {k: np.array(v) for k, v in m.local_tables().items()}
+            m.backend.model.close()
+        for k in tables["plain"]:                            # the front end reads no table: the same numbers, bit for bit
+            assert np.array_equal(tables["plain"][k], tables["pipelined"][k]), "table %d differs between the two forms" % k
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(optimizer="adam", adam_mode="lazy"), dict(optimizer="sgd", lr=2e-4)])
+def test_two_rank_pipelined_front_end_equals_plain_steps(kw):
+    """train_step_local_ids(ids, next_ids): the next batch's bucket / exchanges / routing / sorts run on a side stream into the
+    model's second routed-batch set while the step's own kernels run; the next call starts at the row gather.  Five steps on two
+    ranks (real kernels; gloo stages the exchanges through the host) against the float64 oracle, and bit for bit against the same
+    steps without the pipelining."""
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), kw, 3000, 900, 64, 6000, 5), nprocs=2, join=True)
+
+
 def _one_rank_overflows(rank, world, port, D):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

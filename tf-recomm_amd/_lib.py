@@ -102,6 +102,8 @@ SIGNATURES = {
     "tfr_shard_forward_items": (C.c_int, [_p, _p, _p, _p, _p]),
     "tfr_shard_reduce_users": (C.c_int, [_p, _p]),
     "tfr_shard_apply_items": (C.c_int, [_p, _p, _p, C.c_int64]),
+    "tfr_shard_select": (C.c_int, [_p, C.c_int32]),
+    "tfr_shard_presort": (C.c_int, [_p, _p, C.c_int64]),
     "tfr_shard_finish_step": (C.c_int, [_p, _p]),
     "tfr_dp_flat_size": (C.c_int64, [_p]),
     "tfr_dp_local_grads": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _p]),

@@ -120,10 +120,21 @@ struct tfr_model {
     int64_t* h_ring = nullptr; int64_t* d_ring = nullptr; int64_t ring_cap = 0; int ring_pos = 0;
     hipEvent_t ring_ev[HRING] = {nullptr, nullptr, nullptr, nullptr};
     // row-sharded step: the routed local batch (tfr_shard_route)
-    int32_t *rt_mine = nullptr, *rt_u = nullptr, *rt_it = nullptr, *rt_slot = nullptr, *rt_counts = nullptr;
-    float* rt_r = nullptr;
-    int64_t route_cap = 0, rt_B = 0, rt_slots = 0;
-    int32_t route_world = 0, rt_world = 0;
+    // Two sets, so that a caller can route (and pre-sort) batch s+1 on a side stream while step s still reads its own:
+    // tfr_shard_select picks the set the shard calls fill and consume.
+    struct RouteSet {
+        int32_t *mine = nullptr, *u = nullptr, *it = nullptr, *slot = nullptr, *counts = nullptr;
+        float* r = nullptr;
+        int64_t cap = 0, B = 0, slots = 0;
+        int32_t cap_world = 0, world = 0;
+        // sorted orders: of the routed samples by local user row / by request slot (forward + reduce), made by tfr_shard_presort
+        // ahead of time or by the step itself; of the requests received as an owner (apply_items)
+        int32_t *ks_u = nullptr, *ps_u = nullptr, *ks_i = nullptr, *ps_i = nullptr;
+        int32_t *akeys = nullptr, *aks = nullptr, *aps = nullptr; int64_t acap = 0;
+        bool sorted_fwd = false; const int32_t* sorted_req = nullptr; int64_t sorted_req_n = 0;
+        const int32_t *fks_u = nullptr, *fps_u = nullptr, *fks_i = nullptr, *fps_i = nullptr;   // where the forward's sorted columns are
+    } rt[2];
+    int rt_sel = 0;
     // resident validation set (svd_train_val.py:33-38: the whole set is one batch)
     int32_t *ev_u = nullptr, *ev_i = nullptr;
     float* ev_r = nullptr;
@@ -420,7 +431,10 @@ int tfr_destroy(tfr_model* m) {
     if (m->ev_ids_free) (void)hipEventDestroy(m->ev_ids_free);
     dfree(m->d_rng); dfree(m->d_ring); dfree(m->d_ids_alt); dfree(m->d_rng_snap);
     dfree(m->rng_ws.raw); dfree(m->rng_ws.counts); dfree(m->rng_ws.hdr);
-    dfree(m->rt_mine); dfree(m->rt_u); dfree(m->rt_it); dfree(m->rt_r); dfree(m->rt_slot); dfree(m->rt_counts);
+    for (auto& R : m->rt) {
+        dfree(R.mine); dfree(R.u); dfree(R.it); dfree(R.r); dfree(R.slot); dfree(R.counts);
+        dfree(R.ks_u); dfree(R.ps_u); dfree(R.ks_i); dfree(R.ps_i); dfree(R.akeys); dfree(R.aks); dfree(R.aps);
+    }
     if (m->spec_ev) (void)hipEventDestroy(m->spec_ev);
     if (m->h_ring) (void)hipHostFree(m->h_ring);
     for (int z = 0; z < tfr_model::HRING; ++z) if (m->ring_ev[z]) (void)hipEventDestroy(m->ring_ev[z]);
@@ -2166,7 +2180,7 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
                  tile_step_epg((int)ntiles, G, V), G, V, nt);
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
-        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch; look-ahead batches: one k_psort launch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
+        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch) - look-ahead batches: one k_psort launch;reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
                  "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
                  ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
     } else if (csort) {
@@ -2309,16 +2323,21 @@ static int shard_route_core(tfr_model* m, const int32_t* d_user, const int32_t* 
     int rc;
     const int64_t need = sample_cap > (int64_t)world * slot_cap ? sample_cap : (int64_t)world * slot_cap;
     if ((rc = ensure_capacity(m, need > Bg ? need : (Bg > 0 ? Bg : 1)))) return rc;
-    if (sample_cap > m->route_cap || world > m->route_world) {
+    tfr_model::RouteSet& R = m->rt[m->rt_sel];
+    if (sample_cap > R.cap || world > R.cap_world) {
         HIPCHK(hipStreamSynchronize(m->stream));
-        dfree(m->rt_mine); dfree(m->rt_u); dfree(m->rt_it); dfree(m->rt_r); dfree(m->rt_slot); dfree(m->rt_counts);
-        m->rt_mine = m->rt_u = m->rt_it = m->rt_slot = m->rt_counts = nullptr; m->rt_r = nullptr; m->route_cap = 0;
-        if ((rc = dmalloc(&m->rt_mine, (size_t)sample_cap)) || (rc = dmalloc(&m->rt_u, (size_t)sample_cap)) ||
-            (rc = dmalloc(&m->rt_it, (size_t)sample_cap)) || (rc = dmalloc(&m->rt_r, (size_t)sample_cap)) ||
-            (rc = dmalloc(&m->rt_slot, (size_t)sample_cap)) || (rc = dmalloc(&m->rt_counts, (size_t)world + 4))) return rc;
-        m->route_cap = sample_cap; m->route_world = world;
+        dfree(R.mine); dfree(R.u); dfree(R.it); dfree(R.r); dfree(R.slot); dfree(R.counts);
+        dfree(R.ks_u); dfree(R.ps_u); dfree(R.ks_i); dfree(R.ps_i);
+        R.mine = R.u = R.it = R.slot = R.counts = R.ks_u = R.ps_u = R.ks_i = R.ps_i = nullptr; R.r = nullptr; R.cap = 0;
+        if ((rc = dmalloc(&R.mine, (size_t)sample_cap)) || (rc = dmalloc(&R.u, (size_t)sample_cap)) ||
+            (rc = dmalloc(&R.it, (size_t)sample_cap)) || (rc = dmalloc(&R.r, (size_t)sample_cap)) ||
+            (rc = dmalloc(&R.slot, (size_t)sample_cap)) || (rc = dmalloc(&R.counts, (size_t)world + 4)) ||
+            (rc = dmalloc(&R.ks_u, (size_t)sample_cap)) || (rc = dmalloc(&R.ps_u, (size_t)sample_cap)) ||
+            (rc = dmalloc(&R.ks_i, (size_t)sample_cap)) || (rc = dmalloc(&R.ps_i, (size_t)sample_cap))) return rc;
+        R.cap = sample_cap; R.cap_world = world;
     }
-    m->rt_B = sample_cap; m->rt_slots = world * slot_cap; m->rt_world = world;
+    R.B = sample_cap; R.slots = world * slot_cap; R.world = world;
+    R.sorted_fwd = false; R.sorted_req = nullptr;
     hipStream_t s = m->stream;
     RouteArgs a;
     memset(&a, 0, sizeof(a));
@@ -2328,19 +2347,19 @@ static int shard_route_core(tfr_model* m, const int32_t* d_user, const int32_t* 
     a.per_u = (U_global + world - 1) / world; a.per_i = (I_global + world - 1) / world; a.u_lo = a.per_u * rank;
     a.rank = rank; a.world = world; a.Bcap = sample_cap; a.cap = slot_cap;
     a.u_pad = (int32_t)m->U; a.i_pad = (int32_t)I_global;
-    a.mine = m->rt_mine; a.u_local = m->rt_u; a.it_glob = m->rt_it; a.r_loc = m->rt_r; a.slot = m->rt_slot;
-    a.req = d_req; a.counts = m->rt_counts; a.blk = m->lrank_u; a.err = m->d_err;      // lrank_u: [cap] ints of sort scratch
+    a.mine = R.mine; a.u_local = R.u; a.it_glob = R.it; a.r_loc = R.r; a.slot = R.slot;
+    a.req = d_req; a.counts = R.counts; a.blk = m->lrank_u; a.err = m->d_err;      // lrank_u: [cap] ints of sort scratch
     HIPCHK(hipMemsetAsync(d_req, 0xff, (size_t)world * slot_cap * 4, s));             // every slot unused (-1)
     launch_route_compact(a, s);
     HIPCHK(hipGetLastError());
     {   // the local samples sorted by global item id: distinct ids become adjacent and grouped by owner
-        const int32_t* keys[2] = {m->rt_it, nullptr};
-        const int bits[2] = {bits_for(I_global + 1), 0};
-        int32_t* ks[2] = {m->ks_i, nullptr};
-        int32_t* ps[2] = {m->ps_i, nullptr};
+        const int32_t* keys[2] = {R.it, nullptr};           // (into the set's own arrays: the step buffers may be in use by a step
+        const int bits[2] = {bits_for(I_global + 1), 0};    //  that runs beside this routing)
+        int32_t* ks[2] = {R.ks_i, nullptr};
+        int32_t* ps[2] = {R.ps_i, nullptr};
         if ((rc = radix_sort_columns(m, 1, keys, bits, ks, ps, sample_cap))) return rc;
     }
-    a.ks = m->ks_i; a.ps = m->ps_i;
+    a.ks = R.ks_i; a.ps = R.ps_i;
     launch_route_slots(a, s);
     HIPCHK(hipGetLastError());
     return TFR_OK;
@@ -2392,11 +2411,12 @@ int tfr_shard_route_recs(tfr_model* m, const void* d_recs, int64_t n, int32_t ra
 
 int tfr_shard_routed_devptrs(tfr_model* m, void** mine, void** u_local, void** slot, void** counts) {
     MODEL_ENTER(m);
-    if (!m->rt_counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
-    if (mine) *mine = m->rt_mine;
-    if (u_local) *u_local = m->rt_u;
-    if (slot) *slot = m->rt_slot;
-    if (counts) *counts = m->rt_counts;
+    const tfr_model::RouteSet& R = m->rt[m->rt_sel];
+    if (!R.counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
+    if (mine) *mine = R.mine;
+    if (u_local) *u_local = R.u;
+    if (slot) *slot = R.slot;
+    if (counts) *counts = R.counts;
     return TFR_OK;
 }
 
@@ -2416,12 +2436,13 @@ int tfr_shard_gather(tfr_model* m, const int32_t* d_req_recv, int64_t n, float* 
 // part: 1 = the item half (sort, forward + item-side reduce into the exchange buffer, local scalars), 2 = the user half (user-side
 // reduce + apply; needs nothing the gradient exchange touches, so a caller may run it beside that exchange), 3 = both
 static int shard_forward_reduce_part(tfr_model* m, const float* d_item_rows, float* d_logits, float* d_item_grad, float* d_scalars4, int part) {
-    if (!m->rt_counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
+    tfr_model::RouteSet& R = m->rt[m->rt_sel];
+    if (!R.counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
     if (!d_item_rows || ((part & 1) && (!d_item_grad || !d_scalars4))) return fail(TFR_ERR_ARG, "shard_forward_reduce: null pointer");
-    const int64_t B = m->rt_B, nI = m->rt_slots;
+    const int64_t B = R.B, nI = R.slots;
     const int DS = shard_stride(m);
-    const int32_t* du = m->rt_u; const int32_t* dslot = m->rt_slot; const float* dr = m->rt_r;
-    const int32_t* dB = m->rt_counts;                     // the local batch size, on the device
+    const int32_t* du = R.u; const int32_t* dslot = R.slot; const float* dr = R.r;
+    const int32_t* dB = R.counts;                         // the local batch size, on the device
     int rc;
     if ((rc = ensure_capacity(m, B > nI ? B : nI))) return rc;
     const tfr_opts& o = m->o;
@@ -2444,21 +2465,24 @@ static int shard_forward_reduce_part(tfr_model* m, const float* d_item_rows, flo
     if (part & 1) {
         // a peer that had to void this step (capacity overflow, id out of range) said so beside its rows: void it here too, before
         // anything is updated - every rank then skips the same step and reports it at its next sync
-        launch_adopt_peer_err(d_item_rows, (int64_t)(nI / m->rt_world) * DS, m->rt_world, m->D, m->d_err, s);
+        launch_adopt_peer_err(d_item_rows, (int64_t)(nI / R.world) * DS, R.world, m->D, m->d_err, s);
         HIPCHK(hipGetLastError());
         // K1 runs inside the item-side reduce, on the rows it has in registers anyway (as in the single-GPU big-table step);
         // a separate k_forward launch cost 68 us of the 464 (world-1 rehearsal)
-        {
+        if (R.sorted_fwd) {             // tfr_shard_presort made the sorted orders ahead of time
+            R.fks_u = R.ks_u; R.fps_u = R.ps_u; R.fks_i = R.ks_i; R.fps_i = R.ps_i;
+        } else {
             Prof p(m, TFR_K_SORT);                        // unused sample slots carry keys one past the last row: they sort last
             const int32_t* keys[2] = {du, dslot};
             const int bits[2] = {bits_for(m->U + 1), bits_for(nI + 1)};
             int32_t* ks[2] = {m->ks_u, m->ks_i};
             int32_t* ps[2] = {m->ps_u, m->ps_i};
             if ((rc = radix_sort_columns(m, 2, keys, bits, ks, ps, B))) return rc;
+            R.fks_u = m->ks_u; R.fps_u = m->ps_u; R.fks_i = m->ks_i; R.fps_i = m->ps_i;
         }
         RedArgs ri = r;                 // item side: own = the fetched rows, indexed by slot
         ri.side = 1;
-        ri.ks = m->ks_i; ri.ps = m->ps_i; ri.other = du;
+        ri.ks = R.fks_i; ri.ps = R.fps_i; ri.other = du;
         ri.own = d_item_rows; ri.ostride = DS; ri.own_bias = d_item_rows + m->D; ri.obstride = DS; ri.partner = m->w[TFR_P];
         ri.grad_rows = m->gq; ri.grad_bias = m->gbq;
         // a slot whose samples lie in one block of the sorted order (nearly all) goes straight into the exchange buffer;
@@ -2474,7 +2498,7 @@ static int shard_forward_reduce_part(tfr_model* m, const float* d_item_rows, flo
         HIPCHK(hipGetLastError());
         app.a[0] = ap;                  // reduced gradient row (+ bias gradient) of the split slots, in the exchange layout
         app.a[0].only_split = 1;
-        app.a[0].ks = m->ks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
+        app.a[0].ks = R.fks_i; app.a[0].grad_rows = m->gq; app.a[0].grad_bias = m->gbq;
         app.a[0].w = d_item_grad; app.a[0].wstride = DS; app.a[0].bias_w = d_item_grad + m->D; app.a[0].wbstride = DS;
         {
             Prof p(m, TFR_K_APPLY);
@@ -2494,7 +2518,8 @@ static int shard_forward_reduce_part(tfr_model* m, const float* d_item_rows, flo
     if (part & 2) {
         RedArgs ru = r;                 // user side: rows are local; partner = fetched item rows
         ru.side = 0;
-        ru.ks = m->ks_u; ru.ps = m->ps_u; ru.other = dslot;
+        if (!R.fks_u) return fail(TFR_ERR_STATE, "shard_reduce_users: call tfr_shard_forward_items on this routed batch first");
+        ru.ks = R.fks_u; ru.ps = R.fps_u; ru.other = dslot;
         ru.own = m->w[TFR_P]; ru.partner = d_item_rows; ru.pstride = DS; ru.own_bias = m->w[TFR_BU];
         ru.own_w = m->w[TFR_P]; ru.m = m->m[TFR_P]; ru.v = m->v[TFR_P];
         ru.bias_w = m->w[TFR_BU]; ru.bias_m = m->m[TFR_BU]; ru.bias_v = m->v[TFR_BU];
@@ -2510,7 +2535,7 @@ static int shard_forward_reduce_part(tfr_model* m, const float* d_item_rows, flo
         if (!tf1) {
             app.a[0] = ap;
             app.a[0].only_split = 1;
-            app.a[0].ks = m->ks_u; app.a[0].grad_rows = ru.grad_rows; app.a[0].grad_bias = m->gbp;
+            app.a[0].ks = R.fks_u; app.a[0].grad_rows = ru.grad_rows; app.a[0].grad_bias = m->gbp;
             app.a[0].w = m->w[TFR_P]; app.a[0].m = m->m[TFR_P]; app.a[0].v = m->v[TFR_P];
             app.a[0].bias_w = m->w[TFR_BU]; app.a[0].bias_m = m->m[TFR_BU]; app.a[0].bias_v = m->v[TFR_BU];
             app.a[0].frozen_rows = ru.frozen_rows; app.a[0].frozen_bias = ru.frozen_bias;
@@ -2525,7 +2550,7 @@ static int shard_forward_reduce_part(tfr_model* m, const float* d_item_rows, flo
         DenseArgs& d = dp.a[0];
         d.err = m->d_err; d.D = m->D; d.B = B;
         d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps;
-        d.map = m->map_u; d.ks = m->ks_u; d.grad_rows = m->gp; d.grad_bias = m->gbp; d.rows = m->U;
+        d.map = m->map_u; d.ks = R.fks_u; d.grad_rows = m->gp; d.grad_bias = m->gbp; d.rows = m->U;
         d.w = m->w[TFR_P]; d.m = m->m[TFR_P]; d.v = m->v[TFR_P];
         d.bias_w = m->w[TFR_BU]; d.bias_m = m->m[TFR_BU]; d.bias_v = m->v[TFR_BU];
         d.frozen_rows = (m->frozen >> TFR_P) & 1; d.frozen_bias = (m->frozen >> TFR_BU) & 1;
@@ -2554,7 +2579,8 @@ int tfr_shard_reduce_users(tfr_model* m, const float* d_item_rows) {
 int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* d_grad_recv, int64_t n) {
     MODEL_ENTER(m);
     if (n < 0 || (n > 0 && (!d_req_recv || !d_grad_recv))) return fail(TFR_ERR_ARG, "shard_apply_items: bad arguments");
-    if (!m->rt_counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
+    tfr_model::RouteSet& R = m->rt[m->rt_sel];
+    if (!R.counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
     int rc;
     if ((rc = settle_q(m))) return rc;
     if ((rc = ensure_capacity(m, n > 0 ? n : 1))) return rc;
@@ -2564,12 +2590,15 @@ int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* 
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
     const int DS = shard_stride(m);
     hipStream_t s = m->stream;
-    int32_t* d_nvalid = m->rt_counts + m->rt_world + 2;   // requests actually received (unused slots excluded)
+    int32_t* d_nvalid = R.counts + R.world + 2;           // requests actually received (unused slots excluded)
+    const int32_t* aks = m->ks_i; const int32_t* aps = m->ps_i;
     if (n > 0) {
-        // unused slots (-1) get the key one past the last row: they sort behind every real request and fall outside the count
-        launch_pad_keys(d_req_recv, m->d_i, n, (int32_t)m->I, d_nvalid, s);
-        HIPCHK(hipGetLastError());
-        {
+        if (R.sorted_req == d_req_recv && R.sorted_req_n == n) {       // tfr_shard_presort has sorted these requests already
+            aks = R.aks; aps = R.aps;
+        } else {
+            // unused slots (-1) get the key one past the last row: they sort behind every real request and fall outside the count
+            launch_pad_keys(d_req_recv, m->d_i, n, (int32_t)m->I, d_nvalid, s);
+            HIPCHK(hipGetLastError());
             Prof p(m, TFR_K_SORT);
             const int32_t* keys[2] = {m->d_i, nullptr};
             const int bits[2] = {bits_for(m->I + 1), 0};
@@ -2582,7 +2611,7 @@ int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* 
         memset(&r, 0, sizeof(r));
         r.err = m->d_err; r.B = n; r.D = m->D; r.side = 1; r.dB = d_nvalid;
         r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
-        r.ks = m->ks_i; r.ps = m->ps_i; r.rows_in = d_grad_recv; r.rstride = DS; r.bias_in = d_grad_recv + m->D; r.rbstride = DS;
+        r.ks = aks; r.ps = aps; r.rows_in = d_grad_recv; r.rstride = DS; r.bias_in = d_grad_recv + m->D; r.rbstride = DS;
         r.own = m->w[TFR_Q]; r.own_bias = m->w[TFR_BI];
         r.own_w = m->w[TFR_Q]; r.m = m->m[TFR_Q]; r.v = m->v[TFR_Q];
         r.bias_w = m->w[TFR_BI]; r.bias_m = m->m[TFR_BI]; r.bias_v = m->v[TFR_BI];
@@ -2599,7 +2628,7 @@ int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* 
             memset(&ap, 0, sizeof(ap));
             ap.err = m->d_err; ap.B = n; ap.D = m->D; ap.only_split = 1; ap.dB = d_nvalid;
             ap.alpha = alpha; ap.b1 = o.beta1; ap.b2 = o.beta2; ap.eps = o.eps; ap.lr = o.lr;
-            ap.ks = m->ks_i; ap.grad_rows = m->gq; ap.grad_bias = m->gbq;
+            ap.ks = aks; ap.grad_rows = m->gq; ap.grad_bias = m->gbq;
             ap.w = m->w[TFR_Q]; ap.m = m->m[TFR_Q]; ap.v = m->v[TFR_Q];
             ap.bias_w = m->w[TFR_BI]; ap.bias_m = m->m[TFR_BI]; ap.bias_v = m->v[TFR_BI];
             ap.frozen_rows = r.frozen_rows; ap.frozen_bias = r.frozen_bias;
@@ -2614,13 +2643,61 @@ int tfr_shard_apply_items(tfr_model* m, const int32_t* d_req_recv, const float* 
         DenseArgs& d = dp.a[0];
         d.err = m->d_err; d.D = m->D; d.B = n;
         d.alpha = alpha; d.b1 = o.beta1; d.b2 = o.beta2; d.eps = o.eps;
-        d.map = m->map_i; d.ks = m->ks_i; d.grad_rows = m->gq; d.grad_bias = m->gbq; d.rows = m->I;
+        d.map = m->map_i; d.ks = aks; d.grad_rows = m->gq; d.grad_bias = m->gbq; d.rows = m->I;
         d.w = m->w[TFR_Q]; d.m = m->m[TFR_Q]; d.v = m->v[TFR_Q];
         d.bias_w = m->w[TFR_BI]; d.bias_m = m->m[TFR_BI]; d.bias_v = m->v[TFR_BI];
         d.frozen_rows = (m->frozen >> TFR_Q) & 1; d.frozen_bias = (m->frozen >> TFR_BI) & 1;
         Prof p(m, TFR_K_APPLY);
         launch_adam_dense(dp, 1, m->G, m->VEC, s);
         HIPCHK(hipGetLastError());
+    }
+    return TFR_OK;
+}
+
+// which of the two routed-batch sets the shard calls fill (route_*) and consume (forward / reduce / apply): a caller that
+// prepares batch s+1 on a side stream while step s runs alternates between them
+int tfr_shard_select(tfr_model* m, int32_t which) {
+    MODEL_ENTER(m);
+    if (which != 0 && which != 1) return fail(TFR_ERR_ARG, "shard_select: 0 or 1");
+    m->rt_sel = which;
+    return TFR_OK;
+}
+
+// the index work of a step, ahead of time (all of it depends on the routed batch and the requests only, not on any table):
+// the routed samples sorted by local user row and by request slot, and - with d_req_recv - the requests received as an owner
+// padded and sorted by item row.  tfr_shard_forward_items / _reduce_users / _apply_items then skip their own sorts.
+int tfr_shard_presort(tfr_model* m, const int32_t* d_req_recv, int64_t n) {
+    MODEL_ENTER(m);
+    tfr_model::RouteSet& R = m->rt[m->rt_sel];
+    if (!R.counts) return fail(TFR_ERR_STATE, "no routed batch: call tfr_shard_route first");
+    if (n < 0 || (n > 0 && !d_req_recv)) return fail(TFR_ERR_ARG, "shard_presort: bad arguments");
+    int rc;
+    const int64_t B = R.B, nI = R.slots;
+    if ((rc = ensure_capacity(m, (B > nI ? B : nI) > n ? (B > nI ? B : nI) : n))) return rc;
+    {
+        const int32_t* keys[2] = {R.u, R.slot};
+        const int bits[2] = {bits_for(m->U + 1), bits_for(nI + 1)};
+        int32_t* ks[2] = {R.ks_u, R.ks_i};
+        int32_t* ps[2] = {R.ps_u, R.ps_i};
+        if ((rc = radix_sort_columns(m, 2, keys, bits, ks, ps, B))) return rc;
+        R.sorted_fwd = true;
+    }
+    if (n > 0) {
+        if (n > R.acap) {
+            HIPCHK(hipStreamSynchronize(m->stream));
+            dfree(R.akeys); dfree(R.aks); dfree(R.aps);
+            R.akeys = R.aks = R.aps = nullptr; R.acap = 0;
+            if ((rc = dmalloc(&R.akeys, (size_t)n)) || (rc = dmalloc(&R.aks, (size_t)n)) || (rc = dmalloc(&R.aps, (size_t)n))) return rc;
+            R.acap = n;
+        }
+        launch_pad_keys(d_req_recv, R.akeys, n, (int32_t)m->I, R.counts + R.world + 2, m->stream);
+        HIPCHK(hipGetLastError());
+        const int32_t* keys[2] = {R.akeys, nullptr};
+        const int bits[2] = {bits_for(m->I + 1), 0};
+        int32_t* ks[2] = {R.aks, nullptr};
+        int32_t* ps[2] = {R.aps, nullptr};
+        if ((rc = radix_sort_columns(m, 1, keys, bits, ks, ps, n))) return rc;
+        R.sorted_req = d_req_recv; R.sorted_req_n = n;
     }
     return TFR_OK;
 }

@@ -334,6 +334,12 @@ class SvdModel:
     def shard_apply_items(self, d_req_recv, d_grad_recv, n):
         L.check(self._lib.tfr_shard_apply_items(self._h, d_req_recv, d_grad_recv, n))
 
+    def shard_select(self, which):
+        L.check(self._lib.tfr_shard_select(self._h, int(which)))
+
+    def shard_presort(self, d_req_recv, n):
+        L.check(self._lib.tfr_shard_presort(self._h, d_req_recv, int(n)))
+
     def shard_finish_step(self, d_scalars4):
         L.check(self._lib.tfr_shard_finish_step(self._h, d_scalars4))
 

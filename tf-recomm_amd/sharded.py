@@ -68,11 +68,22 @@ class Comm(object):
     """equal-split all-to-all / all-reduce over ``torch.distributed``.  With a CPU-only backend (gloo)
     device tensors are staged through host memory - the rehearsal path; RCCL takes them as is."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, side_group=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.stage = dist.get_backend(group) == "gloo"
+        # a second communicator for the small exchanges of the NEXT batch's routing (RCCL runs a communicator's collectives in
+        # issue order on one stream: on their own communicator they do not queue in front of this step's row exchanges)
+        self.side_group = side_group
+
+    def side(self):
+        """the same exchanges on the side communicator (falls back to the main one)"""
+        if self.side_group is None:
+            return self
+        c = Comm.__new__(Comm)
+        c.group, c.world, c.rank, c.stage, c.side_group = self.side_group, self.world, self.rank, self.stage, None
+        return c
 
     def all_to_all(self, inp, out=None):
         """``inp`` = ``world`` equal chunks along dim 0, chunk w for rank w; returns the chunks received, by source."""
@@ -117,26 +128,28 @@ class HipShard(object):
         self.D = dim
         self.model = SvdModel(max(1, u_rows), max(1, i_rows), dim, device=device, **opts)
         self.stream = torch.cuda.Stream(device=self.device)
+        self._mstream = self.stream                      # the torch stream the model's kernels are launched on right now
         self.model.set_stream(self.stream.cuda_stream)
         self.stride = self.model.shard_row_stride()
         self._buf = {}
         self._routed = None
+        self._set = 0
 
     # The model's kernels run on self.stream.  When the caller has made that torch's current stream (bench_entry
     # does) the collectives order themselves against it and no cross-stream events are needed; otherwise fence.
     def _foreign(self):
         cur = torch.cuda.current_stream(self.device)
-        return None if cur == self.stream else cur
+        return None if cur == self._mstream else cur
 
     def _sync_in(self):
         cur = self._foreign()
         if cur is not None:
-            self.stream.wait_stream(cur)
+            self._mstream.wait_stream(cur)
 
     def _sync_out(self):
         cur = self._foreign()
         if cur is not None:
-            cur.wait_stream(self.stream)
+            cur.wait_stream(self._mstream)
 
     def _get(self, name, shape, dtype):
         t = self._buf.get(name)
@@ -170,9 +183,24 @@ class HipShard(object):
         self._routed = (sample_cap, world)
         return req
 
+    def select(self, which):
+        """which of the model's two routed-batch sets the following calls fill / consume (and which exchange buffers)"""
+        self._set = int(which)
+        self.model.shard_select(which)
+
+    def presort(self, req_recv):
+        self._sync_in()
+        self.model.shard_presort(req_recv.data_ptr(), req_recv.numel())
+        self._sync_out()
+
+    def on_stream(self, stream):
+        """run the following model calls on `stream` (a torch stream), or back on the model's own with None"""
+        self._mstream = stream or self.stream
+        self.model.set_stream(self._mstream.cuda_stream)
+
     def bucket_ids(self, ids, world, U, pair_cap):
         """this rank's own batch rows -> [world * pair_cap, 4] int32 records grouped by the owner of the user row"""
-        send = self._get("send", (world * pair_cap, 4), torch.int32)
+        send = self._get("send%d" % self._set, (world * pair_cap, 4), torch.int32)
         self._sync_in()
         self.model.shard_bucket_ids(ids.data_ptr(), ids.numel(), world, U, pair_cap, send.data_ptr())
         self._sync_out()
@@ -180,7 +208,7 @@ class HipShard(object):
 
     def route_recs(self, recv, rank, world, U, I, sample_cap, slot_cap):
         """`route` on the records received from the peers (all owned by this rank; user = -1 marks an unused slot)"""
-        req = self._get("req", (world * slot_cap,), torch.int32)
+        req = self._get("req%d" % self._set, (world * slot_cap,), torch.int32)
         self._sync_in()
         self.model.shard_route_recs(recv.data_ptr(), recv.shape[0], rank, world, U, I, sample_cap, slot_cap, req.data_ptr())
         self._sync_out()
@@ -341,37 +369,103 @@ class ShardedSvd(object):
         self._end(t)
         return self._exchange_and_update(req)
 
-    def train_step_local_ids(self, ids):
+    def train_step_local_ids(self, ids, next_ids=None):
         """Pre-split batches (SURVEY 8e's other variant): ``ids`` are THIS rank's own B rows of the rating store (int64 tensor;
         every rank brings a different batch - e.g. its own id stream).  The records are grouped by the owner of their user row,
         one more equal-split all-to-all (16 bytes per sample) takes them there, and the step goes on as for a global batch of
-        ``world * pair_capacity`` slots.  No rank draws, reads or tests a sample of another rank's batch that it does not own."""
+        ``world * pair_capacity`` slots.  No rank draws, reads or tests a sample of another rank's batch that it does not own.
+
+        ``next_ids`` (the batch of the NEXT call, same shape): its whole integer front end - bucket, sample exchange, routing,
+        request exchange and the sorts of the step - is started on a side stream once this step's rows are on their way, into
+        the model's second routed-batch set; the next call finds it done and starts at the row gather.  Nothing in that front end
+        reads a table, so the trajectory is bit for bit the one of calls without ``next_ids``."""
         c, be = self.comm, self.backend
+        pipelined = hasattr(be, "select")
+        pre = getattr(self, "_pre", None)
+        self._pre = None
+        if pipelined and pre is not None and pre["ids"] == (ids.data_ptr(), ids.numel()):
+            be.select(pre["set"])
+            torch.cuda.current_stream(self.device).wait_stream(self._side)     # the front end of this batch ran there
+            be._routed = pre["routed"]
+            req_recv, cur = pre["req_recv"], pre["set"]
+        else:
+            cur = 0
+            if pipelined:
+                be.select(cur)
+            # (with a second routed-batch set every step pre-sorts: the step phases then never touch the sort scratch, which a
+            # front end running beside them on the side stream uses)
+            req_recv = self._front_end(ids, c, timed=True, presort=pipelined)
+        hook = None
+        if pipelined and next_ids is not None:
+            def hook():
+                side = self._side_stream()
+                side.wait_stream(torch.cuda.current_stream(self.device))      # ids drawn / everything queued so far
+                with torch.cuda.stream(side):
+                    be.on_stream(side)
+                    be.select(cur ^ 1)
+                    try:
+                        rr = self._front_end(next_ids, c.side(), timed=False, presort=True)
+                        self._pre = dict(ids=(next_ids.data_ptr(), next_ids.numel()), set=cur ^ 1, req_recv=rr, routed=be._routed)
+                    finally:
+                        be.select(cur)
+                        be.on_stream(None)
+                be._routed = self._routed_now
+        self._routed_now = getattr(be, "_routed", None)
+        return self._exchange_and_update(None, req_recv=req_recv, after_rows=hook)
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def _front_end(self, ids, c, timed, presort=False):
+        """bucket -> sample exchange -> routing -> request exchange (-> the step's sorts): the integer part of a step"""
+        be = self.backend
         pair_cap = self.pair_capacity(ids.numel())
         sample_cap, slot_cap = self.capacities(ids.numel() * self.world)
         sample_cap = min(sample_cap, self.world * pair_cap)
-        t = self._phase("bucket")
+        t = self._phase("bucket") if timed else None
         send = be.bucket_ids(ids, self.world, self.U, pair_cap)
         self._end(t)
-        t = self._phase("all_to_all samples")
-        recv = c.all_to_all(send)
+        t = self._phase("all_to_all samples") if timed else None
+        recv = c.all_to_all(send, self._named_buf("recv", send))
         self._end(t)
-        t = self._phase("route")
+        t = self._phase("route") if timed else None
         req = be.route_recs(recv, self.rank, self.world, self.U, self.I, sample_cap, slot_cap)
         self._end(t)
-        return self._exchange_and_update(req)
-
-    def _exchange_and_update(self, req):
-        c, be = self.comm, self.backend
-        t = self._phase("all_to_all ids")
-        req_recv = c.all_to_all(req)                                       # slots asked of me, by requester
+        t = self._phase("all_to_all ids") if timed else None
+        req_recv = c.all_to_all(req, self._named_buf("req_recv", req))         # slots asked of me, by requester
         self._end(t)
+        if presort:
+            t = self._phase("presort") if timed else None
+            be.presort(req_recv)
+            self._end(t)
+        return req_recv
+
+    def _named_buf(self, name, like):
+        """persistent receive buffers, one per routed-batch set (an exchange of the next batch must not land in a buffer this
+        step still reads)"""
+        key = "%s%d" % (name, getattr(self.backend, "_set", 0))
+        bufs = self.__dict__.setdefault("_bufs", {})
+        b = bufs.get(key)
+        if b is None or b.shape != like.shape or b.device != like.device or b.dtype != like.dtype:
+            b = bufs[key] = torch.empty_like(like)
+        return b
+
+    def _exchange_and_update(self, req, req_recv=None, after_rows=None):
+        c, be = self.comm, self.backend
+        if req_recv is None:
+            t = self._phase("all_to_all ids")
+            req_recv = c.all_to_all(req)                                   # slots asked of me, by requester
+            self._end(t)
         t = self._phase("gather")
         rows_out = be.gather(req_recv)
         self._end(t)
         t = self._phase("all_to_all rows")
-        item_rows = c.all_to_all(rows_out)                                 # chunk w = the rows owner w holds for my slots
+        item_rows = c.all_to_all(rows_out, self._named_buf("item_rows", rows_out))   # chunk w = the rows owner w holds for my slots
         self._end(t)
+        if after_rows is not None:
+            after_rows()                                                   # the next batch's front end starts on the side stream
         if hasattr(be, "forward_items"):
             # the user half needs nothing the gradient exchange touches: it runs on the model's stream while RCCL moves the
             # gradient rows on its own; the 16-byte all-reduce of the scalars goes out early as well
@@ -437,7 +531,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
     (rank 0 prints)."""
     import torch.cuda
     dev = torch.device("cuda", local_rank)
-    comm = Comm()
+    comm = Comm(side_group=dist.new_group())             # the next batch's small exchanges get a communicator of their own
     U, I, D, B = wl["U"], wl["I"], wl["D"], wl["B"]
     Bg = B * world
     opts = dict(optimizer="adam", adam_mode=wl["adam_mode"], lr=wl["lr"], reg=wl["reg"])
@@ -469,13 +563,19 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
         issued[0] += 1
     issue(); issue()
 
+    def ids_of(s):
+        return ids_buf[(s // CH) % 3][(s % CH) * B:(s % CH + 1) * B]
+    pipeline = not os.environ.get("TFR_SHARD_NO_PIPELINE")          # A/B switch: no front end of the next batch on the side stream
+
     def step(_s):
         s = done[0]
         if s % CH == 0:
             be_model.join_draws()
             issue()
+        elif pipeline and (s + 1) % CH == 0:
+            be_model.join_draws()                        # the next batch (first of the next chunk) is read during this step
         done[0] += 1
-        return m.train_step_local_ids(ids_buf[(s // CH) % 3][(s % CH) * B:(s % CH + 1) * B])
+        return m.train_step_local_ids(ids_of(s), ids_of(s + 1) if pipeline else None)
     # untimed set-up before the W warm-up steps: one-off costs of a process's first collectives (a single 40 ms stall between
     # steps 10 and 20 at world 1: 1.33 ms per step in the steady state, 2.0 ms when it fell into a 40-step timed region)
     for s in range(SETUP_STEPS if W < SETUP_STEPS else 0):
@@ -520,7 +620,9 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
                             optimizer="adam", adam_mode=wl["adam_mode"], sample_cap=sample_cap, slot_cap=slot_cap,
                             parallelism="row-sharded tables x%d, pre-split batches (rank r draws its own B rows per step on the device, seed 13575 + r): "
                                         "device-side routing, 4 equal-split all-to-alls (sample records, request slots, packed rows, packed "
-                                        "gradient rows) + one 16-byte all-reduce per step over RCCL, no host sync" % world),
+                                        "gradient rows) + one 16-byte all-reduce per step over RCCL, no host sync; the integer front end of batch "
+                                        "s+1 (bucket, sample + request exchanges, routing, sorts) runs on a side stream beside step s, the user-side "
+                                        "reduce beside the gradient exchange%s" % (world, "" if pipeline else " [front-end pipelining OFF]")),
                 roofline=dict(kernel="all_to_all (%s)" % ("gloo rehearsal: staged through host memory, times meaningless" if comm.stage else "RCCL over xGMI"), bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
                               frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire,
                               exchange_us_per_step=exch_us, phases_us=phases,
