@@ -723,6 +723,8 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
     return TFR_OK;
 }
 
+static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t B);
+
 // hand-written LSD radix sort of one or two key columns: column c = (keys[c], bits[c]) ->
 // sorted keys in ks_out[c], original positions in ps_out[c].  ceil(maxbits/8) passes, 3 launches each.
 static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* keys, const int* bits,
@@ -733,23 +735,26 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
     const int passes = (maxbits + 7) / 8;
     int32_t* tmpk[2] = {m->ks2_u, m->ks2_i};
     int32_t* tmpv[2] = {m->ps2_u, m->ps2_i};
-    if (m->sort_persistent && passes <= 4) {
-        // one launch, one workgroup per column (sort.hip k_psort): slow to finish (~0.1 ms), next to nothing taken from the
-        // kernels it runs beside - the look-ahead sort of the big-table step
+    // TFR_PSORT: 0 = never, 1 = look-ahead sorts only (those that run beside the fused kernels), 2 = every batch-sized radix sort
+    static int psort_mode = -1;
+    if (psort_mode < 0) { const char* e = getenv("TFR_PSORT"); psort_mode = e ? atoi(e) : 2; }
+    if ((psort_mode == 2 || (psort_mode == 1 && m->sort_persistent)) && psort_eligible(B) && passes <= 4) {
+        // one small launch per pass (sort.hip k_psort_pass): <= 16 workgroups per column, no histogram / scan launches
+        if (store_ids) {                                 // the batch comes from the resident store: gather it first
+            int rc = gather_batch(m, store_ids, 0, B);
+            if (rc) return rc;
+            keys = nullptr;
+        }
         PSortArgs a;
         memset(&a, 0, sizeof(a));
         a.B = B; a.passes = passes;
         for (int c = 0; c < ncols; ++c) {
-            a.keys_in[c] = keys[c];
+            a.keys_in[c] = store_ids ? (c == 0 ? m->d_u : m->d_i) : keys[c];
             a.keys_fin[c] = ks_out[c]; a.vals_fin[c] = ps_out[c];
             a.keys_tmp[c] = tmpk[c]; a.vals_tmp[c] = tmpv[c];
             a.limit[c] = limits ? (int32_t)limits[c] : 0x7fffffff;
         }
-        a.err = (limits || store_ids) ? m->d_err : nullptr;      // ids outside the tables void the step
-        if (store_ids) {                                         // pass 0 gathers the batch from the resident store itself
-            a.ids = store_ids; a.store = m->store; a.N = m->N;
-            a.u_out = m->d_u; a.i_out = m->d_i; a.r_out = m->d_r;
-        }
+        a.err = limits ? m->d_err : nullptr;             // ids outside the tables void the step
         launch_psort(a, ncols, m->stream);
         HIPCHK(hipGetLastError());
         return TFR_OK;
@@ -1815,8 +1820,8 @@ static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, i
     static int late = -1;
     if (late < 0) { const char* e = getenv("TFR_SORT_LATE"); late = (e && e[0] == '0') ? 0 : 1; }
     static int psort_env = -1;                             // TFR_PSORT=0: the look-ahead sort as nine launches again (A/B)
-    if (psort_env < 0) { const char* e = getenv("TFR_PSORT"); psort_env = (e && e[0] == '0') ? 0 : 1; }
-    const bool psort_on = psort_env == 1;
+    if (psort_env < 0) { const char* e = getenv("TFR_PSORT"); psort_env = e ? atoi(e) : 2; }
+    const bool psort_on = psort_env != 0;
     if (late) {
         m->ev_mid_on = true;
         for (int32_t s = 0; s < nsteps && !rc; ++s) {
@@ -2180,7 +2185,7 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
                  tile_step_epg((int)ntiles, G, V), G, V, nt);
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
-        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch) - look-ahead batches: one k_psort launch;reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
+        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch), or k_gather_triples + k_psort_pass x passes;reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
                  "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
                  ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
     } else if (csort) {

@@ -1,7 +1,7 @@
-# A/B of the big-table step inside ONE gpurun call: the one-workgroup look-ahead sort (k_psort) and the two-table item form
+# A/B of the big-table step inside ONE gpurun call: the one-launch-per-pass radix sort (k_psort_pass: 0 off, 1 look-ahead sorts only, 2 all) and the two-table item form
 set -e
 cd $GRAFT_REPO_ROOT
-for cfg in "1 1" "0 1" "1 0" "0 0" "1 1" "0 1"; do
+for cfg in "2 1" "1 1" "0 1" "2 0" "0 0" "2 1" "0 1"; do
   set -- $cfg
   echo "TFR_PSORT=$1 TFR_DUALQ=$2"
   TFR_PSORT=$1 TFR_DUALQ=$2 python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline --no-north-star 2>/dev/null | python -c "
