@@ -279,9 +279,7 @@ int tfr_staged_ids_devptr(tfr_model* m, void** ptr, int64_t* n);
 
 /* ---- index work of the backward, exposed for bit-exact checks: stable sort of batch
  *      positions by row id (what tf.unique + unsorted_segment_sum's batch-order walk reduce
- *      to).  side 0 = user ids, 1 = item ids; + 2 = through the one-launch form of the radix sort (one workgroup per
- *      column: what the look-ahead of the big-table step uses; tables too big for the counting sort only).  Host pointers;
- *      outputs [batch]. */
+ *      to).  side 0 = user ids, 1 = item ids.  Host pointers; outputs [batch]. */
 int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t batch,
                       int32_t* sorted_ids_out, int32_t* sorted_pos_out);
 

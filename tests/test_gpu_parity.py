@@ -205,11 +205,9 @@ def test_sort_large_random_matches_numpy(B):
 
 
 @pytest.mark.parametrize("n", [20_000, 300_000, 10_000_000, 20_000_000])
-def test_sort_one_workgroup_per_column_edges(n):
-    """The look-ahead form of the radix sort (k_psort: ONE launch, one 1024-thread workgroup per key column, all passes inside;
-    wave-private LDS counters, ballot ranks) at its edges: 2, 3 and 4 passes (15, 19, 24, 25 key bits), one key, partial rounds
-    and chunks, a hot id on a third of the batch and a block of equal keys - against np.argsort(kind="stable") and against the
-    nine-launch form."""
+def test_radix_sort_edges(n):
+    """The radix sort at 2, 3 and 4 passes (15, 19, 24, 25 key bits): one key, partial waves and tiles, a hot id on a third of the
+    batch and a block of equal keys - against np.argsort(kind="stable")."""
     rs = np.random.RandomState(n % 1000 + 3)
     with T.SvdModel(n, 16, 4, optimizer="sgd") as m:
         for B in (1, 63, 64, 65, 1023, 1024, 1025, 4097, 100_000, 262_144, 300_001):
@@ -218,10 +216,9 @@ def test_sort_one_workgroup_per_column_edges(n):
                 ids[rs.rand(B) < 0.33] = ids[0]
                 ids[B // 2: B // 2 + 500] = n - 1
             want = np.argsort(ids, kind="stable").astype(np.int32)
-            for side in (2, 0):
-                ks, ps = m.sort_segments(side, ids)
-                assert np.array_equal(ps, want), (n, B, side)
-                assert np.array_equal(ks, ids[want]), (n, B, side)
+            ks, ps = m.sort_segments(0, ids)
+            assert np.array_equal(ps, want), (n, B)
+            assert np.array_equal(ks, ids[want]), (n, B)
 
 
 # ------------------------------------------------------------------ determinism

@@ -65,7 +65,6 @@ struct tfr_model {
     // two-table form of the fused big-table step (RedArgs::sel): the alternate item table, the per-row "which table" word,
     // the per-entry {partner row | old table} words of the current batch; q_dirty = some row may live in q_alt
     float* q_alt = nullptr; int32_t* q_sel = nullptr; int32_t* osel = nullptr; bool q_dirty = false;
-    bool sort_persistent = false;     // radix sorts take the one-workgroup-per-column form (k_psort): set around look-ahead sorts
     bool csort_ok = false;
     float *gq = nullptr, *gp = nullptr, *gbq = nullptr, *gbp = nullptr;
     int32_t *map_u = nullptr, *map_i = nullptr;
@@ -723,8 +722,6 @@ static int run_forward(tfr_model* m, int mode, const int32_t* du, const int32_t*
     return TFR_OK;
 }
 
-static int gather_batch(tfr_model* m, const int64_t* d_ids, int64_t lo, int64_t B);
-
 // hand-written LSD radix sort of one or two key columns: column c = (keys[c], bits[c]) ->
 // sorted keys in ks_out[c], original positions in ps_out[c].  ceil(maxbits/8) passes, 3 launches each.
 static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* keys, const int* bits,
@@ -735,30 +732,6 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
     const int passes = (maxbits + 7) / 8;
     int32_t* tmpk[2] = {m->ks2_u, m->ks2_i};
     int32_t* tmpv[2] = {m->ps2_u, m->ps2_i};
-    // TFR_PSORT: 0 = never, 1 = look-ahead sorts only (those that run beside the fused kernels), 2 = every batch-sized radix sort
-    static int psort_mode = -1;
-    if (psort_mode < 0) { const char* e = getenv("TFR_PSORT"); psort_mode = e ? atoi(e) : 2; }
-    if ((psort_mode == 2 || (psort_mode == 1 && m->sort_persistent)) && psort_eligible(B) && passes <= 4) {
-        // one small launch per pass (sort.hip k_psort_pass): <= 16 workgroups per column, no histogram / scan launches
-        if (store_ids) {                                 // the batch comes from the resident store: gather it first
-            int rc = gather_batch(m, store_ids, 0, B);
-            if (rc) return rc;
-            keys = nullptr;
-        }
-        PSortArgs a;
-        memset(&a, 0, sizeof(a));
-        a.B = B; a.passes = passes;
-        for (int c = 0; c < ncols; ++c) {
-            a.keys_in[c] = store_ids ? (c == 0 ? m->d_u : m->d_i) : keys[c];
-            a.keys_fin[c] = ks_out[c]; a.vals_fin[c] = ps_out[c];
-            a.keys_tmp[c] = tmpk[c]; a.vals_tmp[c] = tmpv[c];
-            a.limit[c] = limits ? (int32_t)limits[c] : 0x7fffffff;
-        }
-        a.err = limits ? m->d_err : nullptr;             // ids outside the tables void the step
-        launch_psort(a, ncols, m->stream);
-        HIPCHK(hipGetLastError());
-        return TFR_OK;
-    }
     RSortArgs r;
     memset(&r, 0, sizeof(r));
     r.B = B;
@@ -1819,9 +1792,6 @@ static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, i
     // TFR_SORT_LATE=0: start it beside the item-side kernel (the round-1 order), kept for A/B
     static int late = -1;
     if (late < 0) { const char* e = getenv("TFR_SORT_LATE"); late = (e && e[0] == '0') ? 0 : 1; }
-    static int psort_env = -1;                             // TFR_PSORT=0: the look-ahead sort as nine launches again (A/B)
-    if (psort_env < 0) { const char* e = getenv("TFR_PSORT"); psort_env = e ? atoi(e) : 2; }
-    const bool psort_on = psort_env != 0;
     if (late) {
         m->ev_mid_on = true;
         for (int32_t s = 0; s < nsteps && !rc; ++s) {
@@ -1834,14 +1804,9 @@ static int staged_steps_lookahead(tfr_model* m, int64_t first_step, int64_t B, i
             if (ready && (rc = ready->feed(first_step + s))) break;
             if (s + 1 < nsteps) {
                 swap_sortset(m);                           // the next step's set: free since step s-1, which the main stream has passed
-                // the one-workgroup sort needs most of a step to finish and disturbs nothing: it starts as soon as its buffer
-                // set is free (step s-1 done), beside the item-side kernel; the nine-launch form starts after that kernel
-                if (psort_on) HIPCHK(hipStreamWaitEvent(m->stream2, s == 0 ? m->ev_first : m->ev_free[z ^ 1], 0));
-                else HIPCHK(hipStreamWaitEvent(m->stream2, m->ev_mid, 0));
+                HIPCHK(hipStreamWaitEvent(m->stream2, m->ev_mid, 0));
                 m->stream = m->stream2;
-                m->sort_persistent = psort_on;
                 rc = sort_batch(s + 1);
-                m->sort_persistent = false;
                 m->stream = main_s;
                 if (!rc) rc = hipEventRecord(m->ev_sorted[z ^ 1], m->stream2) == hipSuccess ? TFR_OK : fail(TFR_ERR_HIP, "event record");
             }
@@ -2185,7 +2150,7 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
                  tile_step_epg((int)ntiles, G, V), G, V, nt);
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
-        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch), or k_gather_triples + k_psort_pass x passes;reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
+        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
                  "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
                  ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
     } else if (csort) {
@@ -2288,19 +2253,14 @@ int tfr_forward_resident(tfr_model* m, int64_t lo, int64_t hi, float* logits_out
 
 int tfr_sort_segments(tfr_model* m, int32_t side, const int32_t* ids, int64_t B, int32_t* ks_out, int32_t* ps_out) {
     MODEL_ENTER(m);
-    if (side < 0 || side > 3) return fail(TFR_ERR_ARG, "side must be 0 (user) or 1 (item), + 2 for the one-launch form of the radix sort");
-    const bool persistent = (side & 2) != 0;
-    side &= 1;
+    if (side != 0 && side != 1) return fail(TFR_ERR_ARG, "side must be 0 (user) or 1 (item)");
     if (B < 0 || (B > 0 && (!ids || !ks_out || !ps_out))) return fail(TFR_ERR_ARG, "bad batch / null pointer");
     if (B == 0) return TFR_OK;
     int rc;
     if ((rc = ensure_capacity(m, B))) return rc;
     HIPCHK(hipMemcpyAsync(m->d_u, ids, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->d_i, ids, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
-    m->sort_persistent = persistent;
-    rc = sort_columns(m, m->d_u, m->d_i, B);                       // the training step's own sort path
-    m->sort_persistent = false;
-    if (rc) return rc;
+    if ((rc = sort_columns(m, m->d_u, m->d_i, B))) return rc;      // the training step's own sort path
     HIPCHK(hipMemcpyAsync(ks_out, side == 0 ? m->ks_u : m->ks_i, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(ps_out, side == 0 ? m->ps_u : m->ps_i, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));

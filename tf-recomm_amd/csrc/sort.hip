@@ -297,142 +297,4 @@ void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s) {
     hipLaunchKernelGGL(k_rsort_scatter, grid, dim3(CSORT_TILE), 0, s, a);
 }
 
-// ------------------------------------------------------------------------------------
-// psort: the same LSD radix sort for batch-sized inputs (<= 16 x 32768 keys per column) with ONE small launch per pass and no
-// histogram / scan launches, no global atomics and no inter-workgroup communication:
-//   grid = (tiles <= 16, columns); workgroup t of a column
-//   (S) streams the WHOLE column once (int4 loads, L2-served: <= 2 MB) and counts, in LDS, the digits of the keys in front of its
-//       tile and from its tile on - that is all it needs to know about the other tiles, so no workgroup waits for another;
-//   (A) loads its own tile into registers (wave w owns a contiguous chunk, <= 32 rounds of 64 keys, all loads in flight at
-//       once) and counts its digits per wave;  (B) prefix over digits (global), tiles (from S) and waves;
-//   (C) walks its chunk round by round in order - eight ballots give every key its rank among the equal digits of the round,
-//       the lowest lane of a digit group advances the wave's running offset - and scatters key + position.
-// Stable by construction (tiles, wave chunks, rounds, lanes in order): bit-exact against np.argsort(kind="stable").
-// Why: the nine-launch form costs the big-table step its full 70 us even "hidden" on a second stream (512-block launches take
-// block slots from the bandwidth-bound kernels they run beside); a one-launch-per-pass form that counted the next pass's
-// histogram with global atomics was slower still (device-scope atomics: ~35 us per 0.5 M); one workgroup per column is
-// latency-bound under that contention (2.4 ms).  A/B inside one gpurun call each, DESIGN.md section 8.
-constexpr int PS_RMAX = 32;                              // rounds of 64 keys per wave: tile <= 16 waves x 32 x 64 = 32768 keys
-
-__global__ __launch_bounds__(1024) void k_psort_pass(PSortArgs a, int pass) {
-    __shared__ int32_t wcnt[16][256];
-    __shared__ int32_t before[256], rest[256];
-    __shared__ int32_t wsum[4];
-    const int col = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int shift = 8 * pass;
-    const int64_t B = a.B;
-    auto to_fin = [&](int p) { return ((a.passes - 1 - p) & 1) == 0; };        // ping-pong: the last pass lands in the final buffers
-    const int32_t* __restrict__ kin = pass == 0 ? a.keys_in[col] : (to_fin(pass - 1) ? a.keys_fin[col] : a.keys_tmp[col]);
-    const int32_t* __restrict__ vin = pass == 0 ? nullptr : (to_fin(pass - 1) ? a.vals_fin[col] : a.vals_tmp[col]);
-    int32_t* __restrict__ kout = to_fin(pass) ? a.keys_fin[col] : a.keys_tmp[col];
-    int32_t* __restrict__ vout = to_fin(pass) ? a.vals_fin[col] : a.vals_tmp[col];
-    const int64_t t0 = (int64_t)t * a.tile;
-    const int64_t t1 = (t0 + a.tile < B) ? t0 + a.tile : B;
-    const int chunk = a.tile / 16;                       // keys per wave, a multiple of 64
-    const int R = chunk / 64;
-    const int64_t c0 = t0 + (int64_t)wave * chunk;
-    // (A, first half) own chunk into registers: every load is issued before anything waits
-    int32_t key[PS_RMAX], val[PS_RMAX];
-#pragma unroll
-    for (int r = 0; r < PS_RMAX; ++r) {
-        const int64_t k = c0 + r * 64 + lane;
-        const bool ok = r < R && k < t1;
-        key[r] = ok ? kin[k] : 0;
-        val[r] = ok ? (vin ? vin[k] : (int32_t)k) : 0;
-    }
-    for (int q = tid; q < 16 * 256; q += 1024) (&wcnt[0][0])[q] = 0;
-    if (tid < 256) { before[tid] = 0; rest[tid] = 0; }
-    __syncthreads();
-    // (S) the whole column: digits in front of this tile / from it on
-    bool bad = false;
-    {
-        const int64_t n4 = B >> 2;
-        const int4* __restrict__ k4 = reinterpret_cast<const int4*>(kin);
-        for (int64_t q = tid; q < n4; q += 1024) {
-            const int4 v = k4[q];
-            int32_t* dstc = (q * 4 < t0) ? before : rest;    // tiles start at multiples of 1024 keys: a vector never straddles
-            atomicAdd(&dstc[(v.x >> shift) & 255], 1);
-            atomicAdd(&dstc[(v.y >> shift) & 255], 1);
-            atomicAdd(&dstc[(v.z >> shift) & 255], 1);
-            atomicAdd(&dstc[(v.w >> shift) & 255], 1);
-            if (pass == 0 && t == 0)
-                bad |= ((uint32_t)v.x >= (uint32_t)a.limit[col]) | ((uint32_t)v.y >= (uint32_t)a.limit[col]) |
-                       ((uint32_t)v.z >= (uint32_t)a.limit[col]) | ((uint32_t)v.w >= (uint32_t)a.limit[col]);
-        }
-        for (int64_t k = (n4 << 2) + tid; k < B; k += 1024) {
-            const int32_t v = kin[k];
-            atomicAdd(&((k < t0) ? before : rest)[(v >> shift) & 255], 1);
-            if (pass == 0 && t == 0) bad |= (uint32_t)v >= (uint32_t)a.limit[col];
-        }
-    }
-    if (a.err && pass == 0 && t == 0 && __any(bad) && lane == 0) atomicOr(a.err, 1);
-    // (A, second half) digits of the own chunk, per wave
-#pragma unroll
-    for (int r = 0; r < PS_RMAX; ++r)
-        if (r < R && c0 + r * 64 + lane < t1) atomicAdd(&wcnt[wave][(key[r] >> shift) & 255], 1);
-    __syncthreads();
-    // (B) where this wave's keys of each digit start: keys of smaller digits (whole column) + equal digits in earlier tiles +
-    //     equal digits in earlier waves of this tile
-    if (tid < 256) {
-        const int32_t tot = before[tid] + rest[tid];
-        int32_t incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int32_t y = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += y;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        rest[tid] = incl - tot;                          // exclusive inside the wave (rest[] is free now)
-    }
-    __syncthreads();
-    if (tid < 256) {
-        int32_t run = rest[tid] + before[tid];
-        for (int w = 0; w < wave; ++w) run += wsum[w];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int32_t c = wcnt[w][tid];
-            wcnt[w][tid] = run;
-            run += c;
-        }
-    }
-    __syncthreads();
-    // (C) rank + scatter, round by round
-#pragma unroll
-    for (int r = 0; r < PS_RMAX; ++r) {
-        if (r >= R) continue;                            // uniform (no break: the loop must unroll, key[] / val[] live in registers)
-        const bool valid = c0 + r * 64 + lane < t1;
-        const int32_t digit = (key[r] >> shift) & 255;
-        unsigned long long mask = __ballot(valid);
-#pragma unroll
-        for (int bit = 1; bit < 256; bit <<= 1) {
-            const unsigned long long mb = __ballot((digit & bit) != 0);
-            mask &= (digit & bit) ? mb : ~mb;
-        }
-        const unsigned long long below = mask & ((1ull << lane) - 1ull);
-        int32_t base = 0;
-        if (valid && below == 0) {                       // one lane per digit group moves the wave's offset on
-            base = wcnt[wave][digit];
-            wcnt[wave][digit] = base + __popcll(mask);
-        }
-        const int leader = valid ? __ffsll((long long)mask) - 1 : lane;
-        base = __shfl(base, leader, 64);
-        if (valid) {
-            const int32_t dst = base + __popcll(below);
-            kout[dst] = key[r];
-            vout[dst] = val[r];
-        }
-    }
-}
-
-bool psort_eligible(int64_t B) { return B >= 1 && B <= (int64_t)16 * PS_RMAX * 1024; }
-
-void launch_psort(PSortArgs a, int ncols, hipStream_t s) {
-    int64_t tile = (a.B + 15) / 16;                      // <= 16 tiles per column, each a multiple of 1024 keys
-    tile = (tile + 1023) / 1024 * 1024;
-    a.tile = (int32_t)tile;
-    const int ntiles = (int)((a.B + tile - 1) / tile);
-    for (int p = 0; p < a.passes; ++p) hipLaunchKernelGGL(k_psort_pass, dim3(ntiles, ncols), dim3(1024), 0, s, a, p);
-}
-
 }  // namespace tfr

@@ -304,16 +304,5 @@ struct RSortArgs {
 };
 void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s);
 
-// psort (sort.hip): the radix sort of a batch as one small launch per pass (<= 16 workgroups per column, nothing else)
-struct PSortArgs {
-    const int32_t* keys_in[2];                               // pass 0 input
-    int32_t* keys_fin[2]; int32_t* vals_fin[2];              // where the sorted keys / positions must end up
-    int32_t* keys_tmp[2]; int32_t* vals_tmp[2];              // ping-pong partner
-    int32_t passes, tile;                                    // tile: set by launch_psort
-    int64_t B;
-    int32_t limit[2]; int32_t* err;                          // err != NULL: keys outside [0, limit) flag |= 1
-};
-bool psort_eligible(int64_t B);
-void launch_psort(PSortArgs a, int ncols, hipStream_t s);
 
 }  // namespace tfr

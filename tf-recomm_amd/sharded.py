@@ -589,6 +589,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
     t0 = time.perf_counter()
     for s in range(W, W + K):
         step(s)
+    host_enqueue_s = time.perf_counter() - t0            # the host's share: when it equals the step time, the host is the bound
     m.backend.sync()
     torch.cuda.synchronize()
     comm.barrier()
@@ -625,7 +626,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
                                         "reduce beside the gradient exchange%s" % (world, "" if pipeline else " [front-end pipelining OFF]")),
                 roofline=dict(kernel="all_to_all (%s)" % ("gloo rehearsal: staged through host memory, times meaningless" if comm.stage else "RCCL over xGMI"), bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
                               frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire,
-                              exchange_us_per_step=exch_us, phases_us=phases,
+                              exchange_us_per_step=exch_us, phases_us=phases, host_enqueue_us_per_step=host_enqueue_s / K * 1e6,
                               note="egress bytes per rank and step (fixed-capacity slots: %d of them to each of %d peers, %d B each way per slot) "
                                    "over the whole step time; 7 links x 153 GB/s per GPU; with world=1 nothing crosses a link"
                                    % (slot_cap, world - 1, 2 * packed_stride(D) * 4 + 4)),
