@@ -189,7 +189,10 @@ int tfr_forward_dev(tfr_model* m, const int32_t* d_user, const int32_t* d_item, 
 int tfr_train_step_dev(tfr_model* m, const int32_t* d_user, const int32_t* d_item,
                        const float* d_rate, int64_t batch, float* d_logits /* may be NULL */);
 int tfr_table_devptr(tfr_model* m, int32_t which, void** ptr, int64_t* n);
-int tfr_set_stream(tfr_model* m, void* hip_stream);   /* NULL = the model's own stream */
+int tfr_set_stream(tfr_model* m, void* hip_stream);   /* NULL = the model's own stream; drains the stream in use first */
+/* the same without draining: for a caller that alternates between two streams and orders them itself with events (the
+ * row-sharded step prepares batch s+1 on a side stream while step s runs on the main one) */
+int tfr_switch_stream(tfr_model* m, void* hip_stream);
 int tfr_get_stream(tfr_model* m, void** hip_stream);
 /* last step's device scalars {loss, reg, sum_g} without a host copy */
 int tfr_scalars_devptr(tfr_model* m, void** ptr);

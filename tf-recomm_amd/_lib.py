@@ -89,6 +89,7 @@ SIGNATURES = {
     "tfr_train_step_dev": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p]),
     "tfr_table_devptr": (C.c_int, [_p, C.c_int32, C.POINTER(_p), _i64p]),
     "tfr_set_stream": (C.c_int, [_p, _p]),
+    "tfr_switch_stream": (C.c_int, [_p, _p]),
     "tfr_get_stream": (C.c_int, [_p, C.POINTER(_p)]),
     "tfr_scalars_devptr": (C.c_int, [_p, C.POINTER(_p)]),
     "tfr_shard_row_stride": (C.c_int32, [_p]),

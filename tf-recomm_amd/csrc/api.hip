@@ -640,6 +640,13 @@ int tfr_set_stream(tfr_model* m, void* s) {
     return TFR_OK;
 }
 
+// the same without draining the old stream: for a caller that alternates between two streams and orders them itself (events)
+int tfr_switch_stream(tfr_model* m, void* s) {
+    MODEL_ENTER(m);
+    m->stream = s ? (hipStream_t)s : m->own_stream;
+    return TFR_OK;
+}
+
 int tfr_get_stream(tfr_model* m, void** s) {
     MODEL_ENTER(m);
     if (s) *s = (void*)m->stream;
@@ -1684,9 +1691,7 @@ struct IdsReady {
     tfr_model* m = nullptr;
     int64_t B = 0, nsteps = 0;
     uint32_t rng = 0;
-    // tail: the call's last small-table step also sorts the NEXT call's first batch (its ids are drawn ahead into the alternate
-    // buffer as soon as this call's own chunks are out), so that call starts from a published sort like every later step
-    bool tail = false, ahead_done = false;
+    bool ahead_done = false;
     std::vector<int64_t> first;                            // first[c] = first step of chunk c; first[nchunks] = nsteps
     int enq = 0;                                           // chunks enqueued so far
     int waited[2] = {-1, -1};                              // highest chunk waited for: [0] main stream, [1] stream2
@@ -1736,27 +1741,11 @@ struct IdsReady {
     // after a step's launches: one more chunk for the draw stream (never before them - with ids drawn ahead by the previous
     // call the first step must not queue behind draw launches it does not need; one per step keeps the host ahead of a
     // 20-us step and the generator busy from the start, so the run-ahead draw at the end of the call fits inside it)
-    int feed(int64_t step) {
-        int rc = enqueue_through(step, 1);
-        if (!rc && tail && !ahead_done && enq >= (int)first.size() - 1) rc = run_ahead();
-        return rc;
-    }
+    int feed(int64_t step) { return enqueue_through(step, 1); }
     int run_ahead() {
         if (ahead_done) return TFR_OK;
         ahead_done = true;
         return enqueue_run_ahead(m, B, nsteps, rng);
-    }
-    // ids of the step after this call's last one (device pointer), ready on `st`; NULL when there is no run-ahead
-    int tail_ids(hipStream_t st, const int64_t** out) {
-        *out = nullptr;
-        if (!tail) return TFR_OK;
-        int rc = enqueue_through(nsteps);
-        if (!rc) rc = run_ahead();
-        if (rc) return rc;
-        if (!m->spec_valid) return TFR_OK;
-        if (hipStreamWaitEvent(st, m->spec_ev, 0) != hipSuccess) return fail(TFR_ERR_HIP, "hipStreamWaitEvent failed");
-        *out = m->d_ids_alt;
-        return TFR_OK;
     }
     int need(int64_t step, hipStream_t st, int which) {
         if (step >= nsteps) step = nsteps - 1;
@@ -1859,7 +1848,6 @@ static int staged_steps(tfr_model* m, int64_t first_step, int64_t B, int32_t nst
         // look ahead past the end of this call too when more staged batches follow: the
         // next call then starts presorted (the sort is free, hidden in this launch)
         const int64_t* nxt = (first_step + s + 2) * B <= m->n_ids ? m->d_ids + (first_step + s + 1) * B : nullptr;
-        if (!nxt && ready && s == nsteps - 1 && (rc = ready->tail_ids(m->stream, &nxt))) return rc;     // drawn call: the next call's first batch
         if ((rc = run_train_step(m, m->d_u, m->d_i, m->d_r, B, nullptr,
                                  loss_out ? m->step_out + (size_t)s * 4 : nullptr,
                                  m->d_ids + (first_step + s) * B, nxt))) {
@@ -2108,24 +2096,17 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
         HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));
         HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));
     }
-    // a published look-ahead sort survives only if it is the sort of this call's first batch (the previous call's last step made
-    // it from the ids drawn ahead, now at the head of d_ids); anything else in the buffer changes
-    if (!(pre && m->pf_valid && m->pf_ids == m->d_ids && m->pf_B == B)) m->pf_valid = false;
+    m->pf_valid = false;                                   // the buffer's contents change: no published look-ahead sort survives
     m->n_ids = total;
     IdsReady ready;
     ready.m = m; ready.B = B; ready.nsteps = nsteps; ready.rng = rng;
-    {
-        static int tail_on = -1;                           // TFR_TAIL_SORT=0: A/B switch
-        if (tail_on < 0) { const char* e = getenv("TFR_TAIL_SORT"); tail_on = (e && e[0] == '0') ? 0 : 1; }
-        ready.tail = tail_on && rng != 0 && nsteps >= 8 && tiles_eligible(m, B) && !m->prof;
-    }
     ready.plan(B >= 65536 ? 1 : (65536 / B < 16 ? 65536 / B : 16), pre);     // a chunk holds at most ~64K ids / 16 steps
     if (rng == 0) HIPCHK(hipMemsetAsync(m->d_ids, 0, (size_t)total * 8, m->stream3));   // one-rating store: no draw consumed
     tr.mark(pre ? "ids drawn ahead taken" : "no ids drawn ahead");
     if ((rc = staged_steps(m, 0, B, nsteps, loss_out, &ready))) return rc;
     tr.mark("all steps enqueued");
     if ((rc = ready.enqueue_through(nsteps))) return rc;   // (every chunk is out by now; this is a no-op kept for clarity)
-    if (rng != 0 && (rc = ready.run_ahead())) return rc;  // (the tail sort has usually issued it already)
+    if (rng != 0 && (rc = ready.run_ahead())) return rc;
     tr.mark("run-ahead draw enqueued");
     return TFR_OK;
 }

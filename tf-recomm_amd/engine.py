@@ -370,6 +370,10 @@ class SvdModel:
     def set_stream(self, stream_ptr):
         L.check(self._lib.tfr_set_stream(self._h, stream_ptr))
 
+    def switch_stream(self, stream_ptr):
+        """set_stream without draining the stream in use (the caller orders the streams itself)"""
+        L.check(self._lib.tfr_switch_stream(self._h, stream_ptr))
+
     def get_stream(self):
         p = L._p()
         L.check(self._lib.tfr_get_stream(self._h, C.byref(p)))

@@ -196,7 +196,7 @@ class HipShard(object):
     def on_stream(self, stream):
         """run the following model calls on `stream` (a torch stream), or back on the model's own with None"""
         self._mstream = stream or self.stream
-        self.model.set_stream(self._mstream.cuda_stream)
+        self.model.switch_stream(self._mstream.cuda_stream)     # no drain: the caller orders the streams with wait_stream
 
     def bucket_ids(self, ids, world, U, pair_cap):
         """this rank's own batch rows -> [world * pair_cap, 4] int32 records grouped by the owner of the user row"""
