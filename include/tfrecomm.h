@@ -171,6 +171,9 @@ int tfr_draw_ids(tfr_model* m, int64_t high, int64_t count, int64_t* ids_out);
  * draws the global batch's ids - the same stream on every rank - and takes its slice, dataio.py:115 with no host in it). */
 int tfr_draw_ids_dev(tfr_model* m, int64_t high, int64_t count, int64_t* d_ids_out);
 int tfr_join_draws(tfr_model* m);
+/* ...for the first `ordinal` draws only (issued draws are counted from 1 and complete in issue order): a caller that keeps
+ * several draws in flight waits for the one whose buffer it is about to read, not for the latest */
+int tfr_join_draw(tfr_model* m, int64_t ordinal);
 /* nsteps x { next(iter_train); sess.run(train_op) } (svd_train_val.py:66-72) with every part on the
  * device: ids drawn from randint(0, n_store_ratings) as above (on a side stream, ahead of the steps
  * that use them), rows gathered from the resident store, one training step each.  loss_out[nsteps]

@@ -83,6 +83,34 @@ def test_draw_into_device_memory_and_join(model):
         m.draw_ids_dev(0, 5, bufs[0].data_ptr())
 
 
+def test_join_one_draw_of_several_in_flight(model):
+    """tfr_join_draw(ordinal): with several draws in flight a caller waits for the one whose buffer it reads next (issued draws
+    are counted from 1 and finish in issue order) - more draws than the event ring holds, joined one by one and out of step."""
+    import torch
+    m = model
+    np.random.seed(5)
+    m.rng_seed(5)
+    store = np.random.RandomState(1)
+    U, I = m.user_num, m.item_num
+    n = 5000
+    m.upload_triples(store.randint(0, U, n).astype(np.int32), store.randint(0, I, n).astype(np.int32), np.ones(n, np.float32))
+    bufs = [torch.empty(3000, dtype=torch.int64, device="cuda") for _ in range(12)]
+    want = []
+    for k in range(12):                                      # twelve draws issued back to back: the ring holds eight events
+        want.append(np.random.randint(0, n, (3000,)))
+        m.draw_ids_dev(n, 3000, bufs[k].data_ptr())
+    for k in (2, 0, 11, 7):
+        m.join_draw(k + 1)
+        m.sync()                                             # the model's stream has waited for draw k (and all before it)
+        assert np.array_equal(bufs[k].cpu().numpy(), want[k]), k
+    with pytest.raises(T.TfrError):
+        m.join_draw(0)
+    m.join_draws()
+    m.sync()
+    for k in range(12):
+        assert np.array_equal(bufs[k].cpu().numpy(), want[k]), k
+
+
 def test_wide_draw_that_comes_up_short_is_finished_by_the_sequential_kernel():
     """TFR_RNG_WIDE_TRIM makes the wide form generate too few blocks: the k_mt_draw launch behind it draws the rest from
     the state the last block left - same ids, same final state (a fresh process: the switch is read once)."""

@@ -83,6 +83,7 @@ SIGNATURES = {
     "tfr_draw_ids": (C.c_int, [_p, C.c_int64, C.c_int64, _i64p]),
     "tfr_draw_ids_dev": (C.c_int, [_p, C.c_int64, C.c_int64, _p]),
     "tfr_join_draws": (C.c_int, [_p]),
+    "tfr_join_draw": (C.c_int, [_p, C.c_int64]),
     "tfr_train_steps_drawn": (C.c_int, [_p, C.c_int64, C.c_int32, _f32p]),
     "tfr_train_step_ids": (C.c_int, [_p, _i64p, C.c_int64]),
     "tfr_forward_dev": (C.c_int, [_p, _p, _p, C.c_int64, _p]),

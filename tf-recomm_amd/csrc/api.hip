@@ -91,7 +91,10 @@ struct tfr_model {
     int64_t alt_cap = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_first = nullptr;
-    hipEvent_t draw_ev = nullptr; bool draw_pending = false;   // tfr_draw_ids_dev / tfr_join_draws
+    // tfr_draw_ids_dev / tfr_join_draws / tfr_join_draw: one event per issued draw (ring; draws complete in issue order)
+    static const int DRAW_RING = 8;
+    hipEvent_t draw_evs[DRAW_RING] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t draw_count = 0, draw_joined = 0;
     MtScratch rng_ws = {nullptr, nullptr, nullptr, 0};     // wide form of the id draw (rng.hip), allocated with the generator state
     hipEvent_t ev_mid = nullptr; bool ev_mid_on = false;   // recorded between the item-side and the user-side kernel of a big-table step
     // resident store
@@ -440,7 +443,7 @@ int tfr_destroy(tfr_model* m) {
     for (int z = 0; z < 2; ++z) { if (m->ev_sorted[z]) (void)hipEventDestroy(m->ev_sorted[z]); if (m->ev_free[z]) (void)hipEventDestroy(m->ev_free[z]); }
     if (m->ev_first) (void)hipEventDestroy(m->ev_first);
     if (m->ev_mid) (void)hipEventDestroy(m->ev_mid);
-    if (m->draw_ev) (void)hipEventDestroy(m->draw_ev);
+    for (auto& e : m->draw_evs) if (e) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
     return TFR_OK;
@@ -637,6 +640,7 @@ int tfr_set_stream(tfr_model* m, void* s) {
     MODEL_ENTER(m);
     HIPCHK(hipStreamSynchronize(m->stream));
     m->stream = s ? (hipStream_t)s : m->own_stream;
+    m->draw_joined = 0;                                  // joins were made on the old stream
     return TFR_OK;
 }
 
@@ -644,6 +648,7 @@ int tfr_set_stream(tfr_model* m, void* s) {
 int tfr_switch_stream(tfr_model* m, void* s) {
     MODEL_ENTER(m);
     m->stream = s ? (hipStream_t)s : m->own_stream;
+    m->draw_joined = 0;                                  // joins were made on the old stream
     return TFR_OK;
 }
 
@@ -2007,7 +2012,8 @@ int tfr_draw_ids_dev(tfr_model* m, int64_t high, int64_t count, int64_t* d_ids_o
     if (!m->rng_set) return fail(TFR_ERR_STATE, "no generator state: call tfr_rng_seed / tfr_rng_set_state first");
     if (count == 0) return TFR_OK;
     if ((rc = cancel_run_ahead(m))) return rc;
-    if (!m->draw_ev) HIPCHK(hipEventCreateWithFlags(&m->draw_ev, hipEventDisableTiming));
+    hipEvent_t& dev = m->draw_evs[m->draw_count % tfr_model::DRAW_RING];
+    if (!dev) HIPCHK(hipEventCreateWithFlags(&dev, hipEventDisableTiming));
     HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));     // the buffer's readers queued so far
     HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));
     if (high == 1) {                                       // rng == 0: no draw is consumed
@@ -2017,18 +2023,33 @@ int tfr_draw_ids_dev(tfr_model* m, int64_t high, int64_t count, int64_t* d_ids_o
         launch_mt_draw(m->d_rng, d_ids_out, count, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(m->draw_ev, m->stream3));
-    m->draw_pending = true;
+    HIPCHK(hipEventRecord(dev, m->stream3));
+    m->draw_count += 1;
+    return TFR_OK;
+}
+
+// the model's stream waits for the first `ordinal` draws issued by tfr_draw_ids_dev (1-based count; draws complete in issue
+// order).  A draw whose event slot has been reused by a later draw is covered by waiting for that later one.
+static int join_draw_upto(tfr_model* m, int64_t ordinal) {
+    if (ordinal > m->draw_count) ordinal = m->draw_count;
+    if (ordinal <= m->draw_joined) return TFR_OK;
+    int64_t k = ordinal - 1;                                   // index of the draw to wait for
+    while (k + tfr_model::DRAW_RING < m->draw_count) k += tfr_model::DRAW_RING;   // its slot now holds a later draw of the same residue
+    HIPCHK(hipStreamWaitEvent(m->stream, m->draw_evs[k % tfr_model::DRAW_RING], 0));
+    m->draw_joined = k + 1 > ordinal ? ordinal : k + 1;
+    if (k + 1 > m->draw_joined) m->draw_joined = k + 1;
     return TFR_OK;
 }
 
 int tfr_join_draws(tfr_model* m) {
     MODEL_ENTER(m);
-    if (m->draw_pending) {
-        HIPCHK(hipStreamWaitEvent(m->stream, m->draw_ev, 0));
-        m->draw_pending = false;
-    }
-    return TFR_OK;
+    return join_draw_upto(m, m->draw_count);
+}
+
+int tfr_join_draw(tfr_model* m, int64_t ordinal) {
+    MODEL_ENTER(m);
+    if (ordinal < 1) return fail(TFR_ERR_ARG, "join_draw: ordinal counts issued draws from 1");
+    return join_draw_upto(m, ordinal);
 }
 
 // run ahead: the next call's first batches, drawn into the other id buffer (last read by the call before the current one)

@@ -127,8 +127,12 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
     def step(_s):
         s = done[0]
         if s % CH == 0:
-            be.model.join_draws()                      # chunks s / CH and s / CH + 1 (issued one and two chunks ago)
+            # chunk s / CH (its own draw event) and, because the step hints the next batch's ids, chunk s / CH + 1 when the
+            # chunk ends - joined there; never the latest draw (one shared event made every join wait for it)
+            be.model.join_draw(s // CH + 1)
             issue()                                    # chunk s / CH + 2: into the buffer chunk s / CH - 1 lived in
+        if (s + 1) % CH == 0:
+            be.model.join_draw((s + 1) // CH + 1)      # ids_ptr(s + 1) is hinted to this step's launch
         dp.train_step(store_ids_ptr=ids_ptr(s), batch=B, want_scalars=False, next_ids_ptr=ids_ptr(s + 1))
         done[0] += 1
     # untimed set-up before the W warm-up steps: the first few dozen collectives of a process pay one-off costs (RCCL channel
@@ -159,7 +163,7 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
     for k in range(n_t):
         s = done[0]
         if s % CH == 0:
-            be.model.join_draws()
+            be.model.join_draw(s // CH + 1)
             issue()
         ev[k][0].record()
         flat = be.local_grads(None, None, None, ids_ptr(s), B)

@@ -264,6 +264,10 @@ class SvdModel:
         """the model's stream waits for every draw issued by ``draw_ids_dev`` so far"""
         L.check(self._lib.tfr_join_draws(self._h))
 
+    def join_draw(self, ordinal):
+        """...for the first ``ordinal`` draws issued (counted from 1) only"""
+        L.check(self._lib.tfr_join_draw(self._h, int(ordinal)))
+
     def train_steps_drawn(self, batch, nsteps, want_loss=False):
         """nsteps x { next(iter_train); sess.run(train_op) } with the id draw, the gather from the resident
         store and the step all on the device."""

@@ -570,10 +570,10 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
     def step(_s):
         s = done[0]
         if s % CH == 0:
-            be_model.join_draws()
+            be_model.join_draw(s // CH + 1)              # this chunk's draw (issued two chunks ago), not the latest one
             issue()
-        elif pipeline and (s + 1) % CH == 0:
-            be_model.join_draws()                        # the next batch (first of the next chunk) is read during this step
+        if pipeline and (s + 1) % CH == 0:
+            be_model.join_draw((s + 1) // CH + 1)        # the next batch (first of the next chunk) is read during this step
         done[0] += 1
         return m.train_step_local_ids(ids_of(s), ids_of(s + 1) if pipeline else None)
     # untimed set-up before the W warm-up steps: one-off costs of a process's first collectives (a single 40 ms stall between
