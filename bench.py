@@ -138,17 +138,8 @@ def profiled_traffic(fname, kernel_substr):
     return None if rd is None else rd + (wr or 0.0)
 
 
-def cpu_convergence(wl, train, val, tabs0, steps):
-    """oracle/svd_oracle.c (OpenMP, all host cores) from the same initial tables over the same id stream
-    (np.random.seed(13575); one randint(0, N, (B,)) per step - dataio.py:115): its val RMSE, and the time of
-    the training steps alone (the host-side gather of each batch is outside the clock)."""
-    from oracle import c_oracle
-    U, I, D, B = wl["U"], wl["I"], wl["D"], wl["B"]
-    orc = c_oracle.COracle(U, I, D, adam_mode=wl["adam_mode"], lr=wl["lr"], reg=wl["reg"])
-    tu, ti, tr = train
-    # how many threads: a GPU box exposes every host cpu (256) but gives this job a share of them, and an OpenMP
-    # team larger than the share crawls.  Take the cgroup quota if there is one; otherwise time each candidate
-    # team size (after ~1 s of warm-up: the first second after a team-size change is far slower) and keep the fastest.
+def host_cpus():
+    """(cpus this process may run on, cgroup CPU quota or None): a GPU box exposes every host cpu (256) but gives the job a share"""
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = None
     for qf, pf in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
@@ -162,6 +153,27 @@ def cpu_convergence(wl, train, val, tabs0, steps):
                 break
         except (OSError, ValueError):
             pass
+    return ncpu, quota
+
+
+def cpu_team_size():
+    """OpenMP team for a CPU baseline: the cgroup quota when there is one, else at most 16 of the visible cpus"""
+    ncpu, quota = host_cpus()
+    return min(quota, ncpu) if quota else min(16, ncpu)
+
+
+def cpu_convergence(wl, train, val, tabs0, steps):
+    """oracle/svd_oracle.c (OpenMP, all host cores) from the same initial tables over the same id stream
+    (np.random.seed(13575); one randint(0, N, (B,)) per step - dataio.py:115): its val RMSE, and the time of
+    the training steps alone (the host-side gather of each batch is outside the clock)."""
+    from oracle import c_oracle
+    U, I, D, B = wl["U"], wl["I"], wl["D"], wl["B"]
+    orc = c_oracle.COracle(U, I, D, adam_mode=wl["adam_mode"], lr=wl["lr"], reg=wl["reg"])
+    tu, ti, tr = train
+    # how many threads: a GPU box exposes every host cpu (256) but gives this job a share of them, and an OpenMP
+    # team larger than the share crawls.  Take the cgroup quota if there is one; otherwise time each candidate
+    # team size (after ~1 s of warm-up: the first second after a team-size change is far slower) and keep the fastest.
+    ncpu, quota = host_cpus()
     cands = [min(quota, ncpu)] if quota else sorted({c for c in (4, 8, 16, 32, 64) if c <= ncpu} or {ncpu})
     rs = np.random.RandomState(0)
     best, tried = None, {}
@@ -289,28 +301,26 @@ def fm_forward_bench(device, steps=50, warmup=5, F=1_000_000, D=64, n=1 << 20, n
         t = m.sync()
         if s >= warmup:
             ms.append(t)
-    # CPU baseline: the reference's own formula (forward.py:21-22, float64 NumPy / scipy.sparse) on a bounded sample of
-    # the same rows and the same model; scipy's sparse x dense product is single-threaded
+    # CPU baseline: the reference's own formula (forward.py:21-22) restated in C with OpenMP over rows (oracle/svd_oracle.c
+    # fmo_forward, float64 accumulation like the reference's NumPy) on ALL the rows of the batch, the box's core share
     cpu = None
     if not no_cpu:
-        import scipy.sparse as sp
-        ns = 1 << 17
+        from oracle import c_oracle
+        ncores = cpu_team_size()
+        c_oracle.set_threads(ncores)
         mu, Wv, Vv = m.get()
-        X = sp.csr_matrix((data[:ns].reshape(-1).cpu().numpy().astype(np.float64), indices[:ns].reshape(-1).cpu().numpy(),
-                           np.arange(ns + 1, dtype=np.int64) * nnz), shape=(ns, F))
-        V64, W64 = Vv.astype(np.float64), Wv.astype(np.float64)
+        h_ind, h_dat = indices.reshape(-1).cpu().numpy(), data.reshape(-1).cpu().numpy()
+        h_ptr = np.arange(n + 1, dtype=np.int64) * nnz
+        c_oracle.fm_forward(mu, Wv, Vv, h_ptr[: 4097], h_ind, h_dat)           # thread team warm-up
         t0 = time.perf_counter()
-        X2 = X.multiply(X)
-        y_cpu = mu + X.dot(W64) + 0.5 * (np.power(X.dot(V64), 2).sum(axis=1) - X2.dot(np.power(V64, 2)).sum(axis=1))
+        y_cpu = c_oracle.fm_forward(mu, Wv, Vv, h_ptr, h_ind, h_dat)
         cpu_s = time.perf_counter() - t0
-        ix = np.sort(indices[:ns].cpu().numpy(), axis=1)
-        clean = ~(ix[:, 1:] == ix[:, :-1]).any(axis=1)      # a feature drawn twice in a row: scipy merges the two entries, the kernel keeps two non-zeros
-        y_cpu = np.asarray(y_cpu).ravel()
-        err = float(np.abs(y_cpu - out[:ns].double().cpu().numpy())[clean].max() / max(1e-30, np.abs(y_cpu[clean]).max()))
-        cpu = dict(value=ns / cpu_s, unit="rows/s", cores=1, kind="port",
-                   sample="%d of the same rows in %.2f s: forward.py:21-22's formula (general x^2 form) in float64 NumPy / scipy.sparse CSR, "
-                          "single-threaded; max scale-relative difference to the GPU's float32 output %.1e (rows with a repeated feature excluded: %d)"
-                          % (ns, cpu_s, err, int((~clean).sum())))
+        got = out.double().cpu().numpy()
+        err = float(np.abs(y_cpu - got).max() / max(1e-30, np.abs(y_cpu).max()))
+        cpu = dict(value=n / cpu_s, unit="rows/s", cores=ncores, kind="port",
+                   sample="all %d rows of the batch in %.2f s: forward.py:21-22's formula (general x^2 form), float64 accumulation, C + OpenMP over "
+                          "rows (oracle/svd_oracle.c fmo_forward), %d threads; max scale-relative difference to the GPU's float32 output %.1e"
+                          % (n, cpu_s, ncores, err))
     # training step on the same rows (SGD): forward+coefficients, radix sort of the non-zeros, segmented reduce
     yt = (torch.rand(n, device=dev, generator=g) < 0.5).float()
     tms = []

@@ -33,6 +33,9 @@ def load():
         lib.svdo_set_threads.argtypes = [C.c_int]
         lib.svdo_forward.argtypes = [C.c_void_p, _i32p, _i32p, C.c_int64, _f32p]
         lib.svdo_train_step.argtypes = [C.c_void_p, _i32p, _i32p, _f32p, C.c_int64, _f32p, _f32p, _f32p]
+        lib.fmo_forward.restype = C.c_int
+        lib.fmo_forward.argtypes = [C.c_double, _f32p, _f32p, C.c_int64, C.c_int, C.POINTER(C.c_int64), _i32p, _f32p, C.c_int64,
+                                    C.POINTER(C.c_double)]
         _lib = lib
     return _lib
 
@@ -105,3 +108,19 @@ class COracle:
         if rc:
             raise MemoryError("svdo_train_step rc=%d" % rc)
         return logits, loss.value, reg.value
+
+
+def fm_forward(mu, W, V, indptr, indices, data):
+    """forward.py:21-22 (general x^2 form) on CSR rows, float64 accumulation, OpenMP over rows: svd_oracle.c fmo_forward"""
+    lib = load()
+    W, V = np.ascontiguousarray(W, np.float32), np.ascontiguousarray(V, np.float32)
+    indptr = np.ascontiguousarray(indptr, np.int64)
+    indices, data = np.ascontiguousarray(indices, np.int32), np.ascontiguousarray(data, np.float32)
+    n = indptr.size - 1
+    out = np.empty(n, np.float64)
+    rc = lib.fmo_forward(float(mu), W.ctypes.data_as(_f32p), V.ctypes.data_as(_f32p), V.shape[0], V.shape[1],
+                         indptr.ctypes.data_as(C.POINTER(C.c_int64)), indices.ctypes.data_as(_i32p), data.ctypes.data_as(_f32p), n,
+                         out.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc:
+        raise IndexError("fmo_forward: feature id out of range or dim > 256")
+    return out

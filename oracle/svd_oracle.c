@@ -340,3 +340,35 @@ int svdo_train_step(svdo* o, const int32_t* u, const int32_t* it, const float* r
     o->step += 1;
     return 0;
 }
+
+/* ---- FM second-order forward (forward.py:21-22), float64 like the reference's NumPy:
+ *      y(x) = mu + x.W + 0.5 * (||x V||^2 - sum_j x_j^2 ||V_j||^2)  on CSR rows (the general x^2 form; equals forward.py:22's
+ *      x.dot(V**2) on the 0/1 design matrices fm.py:61-93 builds).  W [F], V [F, D] float32 as the tables are stored; rows are
+ *      independent -> OpenMP over rows (the all-core CPU baseline of BASELINE configs[4]). */
+int fmo_forward(double mu, const float* W, const float* V, int64_t F, int D, const int64_t* indptr, const int32_t* indices,
+                const float* data, int64_t n, double* out) {
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t r = 0; r < n; ++r) {
+        double s[256];
+        if (D > 256) { bad |= 1; continue; }
+        for (int d = 0; d < D; ++d) s[d] = 0.0;
+        double lin = 0.0, sq = 0.0;
+        for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+            const int64_t f = indices[k];
+            if (f < 0 || f >= F) { bad |= 2; continue; }
+            const double x = (double)data[k];
+            lin += x * (double)W[f];
+            const float* v = V + (size_t)f * D;
+            for (int d = 0; d < D; ++d) {
+                const double xv = x * (double)v[d];
+                s[d] += xv;
+                sq += xv * xv;
+            }
+        }
+        double ss = 0.0;
+        for (int d = 0; d < D; ++d) ss += s[d] * s[d];
+        out[r] = mu + lin + 0.5 * (ss - sq);
+    }
+    return bad;
+}

@@ -228,3 +228,24 @@ def test_adam_table_drift_is_float32_arithmetic_not_the_kernels():
             assert moved[k] < 0.5 * np.median(moved[moved > 0])
     assert worst["adam"] > 5e-5          # a pure float32 restatement cannot meet 1e-5 on Adam tables ...
     assert worst["sgd"] < 2e-6           # ... while SGD through the same restatement is at rounding level
+
+
+def test_c_fm_forward_matches_the_numpy_statement_and_the_explicit_pairwise_sum():
+    """oracle/svd_oracle.c fmo_forward (the all-core CPU baseline of BASELINE configs[4]) against oracle/svd_oracle.py's
+    fm_forward and, on a few rows, against the explicit sum over pairs of forward.py:21-22's model."""
+    from oracle import c_oracle
+    rs = np.random.RandomState(4)
+    F, D, n, nnz = 700, 24, 300, 7
+    W, V = rs.normal(0, .3, F).astype(np.float32), rs.normal(0, .2, (F, D)).astype(np.float32)
+    indices = rs.randint(0, F, n * nnz).astype(np.int32)
+    data = rs.randint(1, 4, n * nnz).astype(np.float32)
+    indptr = np.arange(n + 1, dtype=np.int64) * nnz
+    got = c_oracle.fm_forward(0.25, W, V, indptr, indices, data)
+    want = so.fm_forward(np.float64(0.25), W.astype(np.float64), V.astype(np.float64), indptr, indices, data)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    for r in range(5):
+        f, x = indices[r * nnz:(r + 1) * nnz], data[r * nnz:(r + 1) * nnz].astype(np.float64)
+        pair = sum(x[a] * x[b] * float(V[f[a]].astype(np.float64) @ V[f[b]].astype(np.float64)) for a in range(nnz) for b in range(a + 1, nnz))
+        assert abs(got[r] - (0.25 + float(x @ W[f].astype(np.float64)) + pair)) <= 1e-10
+    with pytest.raises(IndexError):
+        c_oracle.fm_forward(0.0, W, V, indptr, indices + F, data)
