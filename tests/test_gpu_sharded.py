@@ -399,7 +399,7 @@ def test_data_parallel_rejects_lazy_adam():
             m.dp_apply(1)
 
 
-def _big_world1(rank, port):
+def _big_world1(rank, port, U=2_000_000, I=200_000):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=0, world_size=1)
@@ -408,7 +408,7 @@ def _big_world1(rank, port):
         from tfrecomm_amd import sharded, _lib as L
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
-        U, I, D, B = 2_000_000, 200_000, 128, 262144            # the slack-capacity regime (batch > 65536), radix paths
+        D, B = 128, 262144                                      # the slack-capacity regime (batch > 65536), radix paths
         kw = dict(optimizer="adam", adam_mode="lazy", lr=2e-3, reg=0.03)
         rs = np.random.RandomState(23)
         batches = [(rs.randint(0, U, B).astype(np.int32), rs.randint(0, I, B).astype(np.int32),
@@ -437,8 +437,9 @@ def _big_world1(rank, port):
         dist.destroy_process_group()
 
 
-def test_one_rank_sharded_step_at_scale_equals_the_fused_single_gpu_step():
+@pytest.mark.parametrize("U,I", [(2_000_000, 200_000), (12_500_000, 1_250_000)])
+def test_one_rank_sharded_step_at_scale_equals_the_fused_single_gpu_step(U, I):
     """The row-sharded step (device routing in its slack-capacity regime, packed exchange buffers, dynamic counts) on a
-    262144-rating batch over 2M x 200k-row tables, world 1: same logits, loss, regulariser and updated rows as the fused
-    single-GPU step of the same model."""
-    mp.spawn(_big_world1, args=(_free_port(),), nprocs=1, join=True)
+    262144-rating batch, world 1: same logits, loss, regulariser and updated rows as the fused single-GPU step of the same
+    model.  2M x 200k rows, and BASELINE config 4's per-rank shard at 8 GPUs (12.5M x 1.25M rows, batch 262144 per GPU)."""
+    mp.spawn(_big_world1, args=(_free_port(), U, I), nprocs=1, join=True)
