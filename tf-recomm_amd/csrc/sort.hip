@@ -297,4 +297,160 @@ void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s) {
     hipLaunchKernelGGL(k_rsort_scatter, grid, dim3(CSORT_TILE), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------------
+// rsort, wide tiles: the same LSD pass for millions of keys (FM non-zeros: 8.4 M; AUC scores).  The 1024-key scatter above
+// writes 4 bytes at a time to 256 x ntiles different places - at 8.4 M keys that is 285 us per pass, four times what the bytes
+// cost.  Here a 1024-thread workgroup owns a tile of 4096 keys, ranks them itself (wave-private LDS counters + ballots: no
+// lrank array to write and read back), stages key + value in LDS in digit order and writes every digit's run (16 keys on
+// average) as one contiguous piece.  Launches per pass: histogram, scan (the kernel above), scatter.
+constexpr int RW_TILE = 4096;
+constexpr int RW_KPT = 4;                                // keys per thread: a wave owns 256 contiguous keys, four rounds
+
+__global__ __launch_bounds__(1024) void k_rsortw_hist(RSortArgs a) {
+    __shared__ int32_t cnt[256];
+    const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (tid < 256) cnt[tid] = 0;
+    __syncthreads();
+    const int64_t k0 = (int64_t)tile * RW_TILE + (tid >> 6) * 256 + (tid & 63);
+#pragma unroll
+    for (int r = 0; r < RW_KPT; ++r) {
+        const int64_t k = k0 + r * 64;
+        if (k < a.B) atomicAdd(&cnt[(a.keys_in[col][k] >> a.shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid < 256) a.hist[col][(size_t)tid * a.ntiles + tile] = cnt[tid];        // bin-major, as k_rsort_scan expects
+}
+
+__global__ __launch_bounds__(1024) void k_rsortw_scatter(RSortArgs a) {
+    __shared__ int32_t wcnt[16][256];
+    __shared__ int32_t dstart[256], gbase[256];
+    __shared__ int32_t stage_k[RW_TILE], stage_v[RW_TILE];
+    constexpr int PREF = 2048;
+    __shared__ int32_t pref[PREF];
+    __shared__ int32_t pw[16];
+    __shared__ int32_t wsum[4];
+    const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t t0 = (int64_t)tile * RW_TILE;
+    const int nt = (int)((a.B - t0 < RW_TILE) ? a.B - t0 : RW_TILE);       // keys in this tile
+    // the tile's keys + values into registers (all loads in flight)
+    int32_t key[RW_KPT], val[RW_KPT];
+#pragma unroll
+    for (int r = 0; r < RW_KPT; ++r) {
+        const int p = wave * 256 + r * 64 + lane;
+        const bool ok = p < nt;
+        key[r] = ok ? a.keys_in[col][t0 + p] : 0;
+        val[r] = ok ? (a.vals_in[col] ? a.vals_in[col][t0 + p] : (int32_t)(t0 + p)) : 0;
+    }
+    for (int q = tid; q < 16 * 256; q += 1024) (&wcnt[0][0])[q] = 0;
+    // totals of the scan blocks in front of an entry of the histogram matrix: prefix them once per workgroup
+    const int64_t nb = ((int64_t)256 * a.ntiles + a.chunk - 1) / a.chunk;
+    {
+        const int32_t x0 = (2 * tid < nb && 2 * tid < PREF) ? a.blocktot[col][2 * tid] : 0;
+        const int32_t x1 = (2 * tid + 1 < nb && 2 * tid + 1 < PREF) ? a.blocktot[col][2 * tid + 1] : 0;
+        int32_t incl = x0 + x1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) pw[wave] = incl;
+        __syncthreads();
+        int32_t run = incl - (x0 + x1);
+        for (int w = 0; w < wave; ++w) run += pw[w];
+        pref[2 * tid] = run;                             // exclusive: totals of the blocks before 2 * tid
+        pref[2 * tid + 1] = run + x0;
+    }
+    __syncthreads();
+    // (A) digits of the own chunk, per wave
+#pragma unroll
+    for (int r = 0; r < RW_KPT; ++r)
+        if (wave * 256 + r * 64 + lane < nt) atomicAdd(&wcnt[wave][(key[r] >> a.shift) & 255], 1);
+    __syncthreads();
+    // (B) per digit: where it starts inside the tile (dstart), where the tile's run of it starts in the output (gbase), and
+    //     the waves' offsets inside the tile
+    if (tid < 256) {
+        int32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += wcnt[w][tid];
+        int32_t incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        dstart[tid] = incl - tot;
+        const int64_t idx = (int64_t)tid * a.ntiles + tile;
+        const int qn = (int)(idx / a.chunk);
+        const int covered = qn < PREF ? qn : PREF - 1;
+        int32_t base = pref[covered];
+        for (int q = covered; q < qn; ++q) base += a.blocktot[col][q];
+        gbase[tid] = base + a.offs[col][idx];
+    }
+    __syncthreads();
+    if (tid < 256) {
+        int32_t run = dstart[tid];
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        dstart[tid] = run;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int32_t c = wcnt[w][tid];
+            wcnt[w][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    // (C) rank inside the tile, round by round (stable: waves, rounds, lanes in order) -> LDS in digit order
+#pragma unroll
+    for (int r = 0; r < RW_KPT; ++r) {
+        const bool valid = wave * 256 + r * 64 + lane < nt;
+        const int32_t digit = (key[r] >> a.shift) & 255;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int bit = 1; bit < 256; bit <<= 1) {
+            const unsigned long long mb = __ballot((digit & bit) != 0);
+            mask &= (digit & bit) ? mb : ~mb;
+        }
+        const unsigned long long below = mask & ((1ull << lane) - 1ull);
+        int32_t base = 0;
+        if (valid && below == 0) {
+            base = wcnt[wave][digit];
+            wcnt[wave][digit] = base + __popcll(mask);
+        }
+        const int leader = valid ? __ffsll((long long)mask) - 1 : lane;
+        base = __shfl(base, leader, 64);
+        if (valid) {
+            const int loc = base + __popcll(below);
+            stage_k[loc] = key[r];
+            stage_v[loc] = val[r];
+        }
+    }
+    __syncthreads();
+    // (D) out: consecutive threads write consecutive places of a digit's run
+#pragma unroll
+    for (int j = 0; j < RW_KPT; ++j) {
+        const int p = tid + j * 1024;
+        if (p < nt) {
+            const int32_t k = stage_k[p];
+            const int32_t d = (k >> a.shift) & 255;
+            const int32_t dst = gbase[d] + (p - dstart[d]);
+            a.keys_out[col][dst] = k;
+            a.vals_out[col][dst] = stage_v[p];
+        }
+    }
+}
+
+bool rsortw_eligible(int64_t B) { return B >= ((int64_t)1 << 20); }
+
+// a.ntiles / a.chunk are set here (tiles of 4096 keys); hist / offs / blocktot are the buffers of the 1024-key form (larger)
+void launch_rsortw_pass(RSortArgs a, int ncols, hipStream_t s) {
+    a.ntiles = (int32_t)((a.B + RW_TILE - 1) / RW_TILE);
+    const dim3 grid(a.ntiles, ncols);
+    hipLaunchKernelGGL(k_rsortw_hist, grid, dim3(1024), 0, s, a);
+    const int64_t total = (int64_t)256 * a.ntiles;
+    hipLaunchKernelGGL(k_rsort_scan, dim3((unsigned)((total + a.chunk - 1) / a.chunk), ncols), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_rsortw_scatter, grid, dim3(1024), 0, s, a);
+}
+
 }  // namespace tfr

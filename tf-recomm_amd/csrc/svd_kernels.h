@@ -303,6 +303,9 @@ struct RSortArgs {
     const int64_t* ids; const int4* store; int64_t N; float* r_out; int32_t* u_out; int32_t* i_out;
 };
 void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s);
+// the same pass with 4096-key tiles whose workgroups rank, stage in LDS and write whole digit runs (>= 2^20 keys, no fused gather)
+bool rsortw_eligible(int64_t B);
+void launch_rsortw_pass(RSortArgs a, int ncols, hipStream_t s);
 
 
 }  // namespace tfr
