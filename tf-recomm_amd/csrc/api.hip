@@ -773,7 +773,7 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
         if (limits) for (int c = 0; c < ncols; ++c) r.limit[c] = (int32_t)limits[c];
         static int wide = -1;                                    // TFR_RSORT_WIDE=0: A/B switch
         if (wide < 0) { const char* e = getenv("TFR_RSORT_WIDE"); wide = (e && e[0] == '0') ? 0 : 1; }
-        if (wide && rsortw_eligible(B) && !store_ids && !limits) launch_rsortw_pass(r, ncols, m->stream);   // millions of keys (FM, AUC)
+        if (wide && rsortw_eligible(B)) launch_rsortw_pass(r, ncols, m->stream);   // millions of keys (FM, AUC)
         else launch_rsort_pass(r, ncols, m->stream);
     }
     HIPCHK(hipGetLastError());

@@ -9,6 +9,7 @@
 //   rsort  - hand-written LSD radix sort (8-bit digits) for big tables: 3 launches per pass,
 //            ceil(bits/8) passes, both columns per launch.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include "svd_kernels.h"
 #include "finalize.inc.h"
@@ -312,11 +313,25 @@ __global__ __launch_bounds__(1024) void k_rsortw_hist(RSortArgs a) {
     if (tid < 256) cnt[tid] = 0;
     __syncthreads();
     const int64_t k0 = (int64_t)tile * RW_TILE + (tid >> 6) * 256 + (tid & 63);
+    bool bad = false;
 #pragma unroll
     for (int r = 0; r < RW_KPT; ++r) {
         const int64_t k = k0 + r * 64;
-        if (k < a.B) atomicAdd(&cnt[(a.keys_in[col][k] >> a.shift) & 255], 1);
+        if (k >= a.B) continue;
+        int32_t key;
+        if (a.ids) {                                     // fused gather (first pass only): this pass reads the store records itself
+            int64_t id = a.ids[k];
+            if ((uint64_t)id >= (uint64_t)a.N) { if (a.err) atomicOr(a.err, 2); id = 0; }
+            const int4 rec = a.store[id];
+            key = col == 0 ? rec.x : rec.y;
+            if (col == 0) { a.u_out[k] = rec.x; a.i_out[k] = rec.y; a.r_out[k] = __int_as_float(rec.z); }
+        } else {
+            key = a.keys_in[col][k];
+        }
+        if (a.err && a.shift == 0) bad |= (uint32_t)key >= (uint32_t)a.limit[col];   // range check rides in the first pass
+        atomicAdd(&cnt[(key >> a.shift) & 255], 1);
     }
+    if (a.err && a.shift == 0 && __any(bad) && (tid & 63) == 0) atomicOr(a.err, 1);
     __syncthreads();
     if (tid < 256) a.hist[col][(size_t)tid * a.ntiles + tile] = cnt[tid];        // bin-major, as k_rsort_scan expects
 }
@@ -441,13 +456,21 @@ __global__ __launch_bounds__(1024) void k_rsortw_scatter(RSortArgs a) {
     }
 }
 
-bool rsortw_eligible(int64_t B) { return B >= ((int64_t)1 << 20); }
+bool rsortw_eligible(int64_t B) {
+    static int64_t lo = -1;                              // TFR_RSORT_WIDE_MIN: smallest key count that takes the wide tiles
+    if (lo < 0) { const char* e = getenv("TFR_RSORT_WIDE_MIN"); lo = e ? atoll(e) : ((int64_t)1 << 20); }
+    return B >= lo;
+}
 
 // a.ntiles / a.chunk are set here (tiles of 4096 keys); hist / offs / blocktot are the buffers of the 1024-key form (larger)
 void launch_rsortw_pass(RSortArgs a, int ncols, hipStream_t s) {
     a.ntiles = (int32_t)((a.B + RW_TILE - 1) / RW_TILE);
     const dim3 grid(a.ntiles, ncols);
     hipLaunchKernelGGL(k_rsortw_hist, grid, dim3(1024), 0, s, a);
+    if (a.ids) {                                         // the gathered columns are what the scatter of this pass reads
+        a.keys_in[0] = a.u_out; a.keys_in[1] = a.i_out;
+        a.ids = nullptr;
+    }
     const int64_t total = (int64_t)256 * a.ntiles;
     hipLaunchKernelGGL(k_rsort_scan, dim3((unsigned)((total + a.chunk - 1) / a.chunk), ncols), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_rsortw_scatter, grid, dim3(1024), 0, s, a);
