@@ -773,7 +773,7 @@ static int radix_sort_columns(tfr_model* m, int ncols, const int32_t* const* key
         if (limits) for (int c = 0; c < ncols; ++c) r.limit[c] = (int32_t)limits[c];
         static int wide = -1;                                    // TFR_RSORT_WIDE=0: A/B switch
         if (wide < 0) { const char* e = getenv("TFR_RSORT_WIDE"); wide = (e && e[0] == '0') ? 0 : 1; }
-        if (wide && rsortw_eligible(B)) launch_rsortw_pass(r, ncols, m->stream);   // millions of keys (FM, AUC)
+        if (wide && rsortw_eligible(B)) launch_rsortw_pass(r, ncols, m->stream);   // from 65536 keys: 4096-key tiles, LDS-staged scatter
         else launch_rsort_pass(r, ncols, m->stream);
     }
     HIPCHK(hipGetLastError());
@@ -2155,8 +2155,9 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
                  tile_step_epg((int)ntiles, G, V), G, V, nt);
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
-        snprintf(tmp, sizeof(tmp), "sort=k_rsort_rank/scan/scatter x%d passes (the first gathers the batch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
+        snprintf(tmp, sizeof(tmp), "sort=%s x%d passes (the first gathers the batch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
                  "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
+                 rsortw_eligible(B) ? "k_rsortw_hist/k_rsort_scan/k_rsortw_scatter" : "k_rsort_rank/scan/scatter",
                  ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
     } else if (csort) {
         snprintf(tmp, sizeof(tmp), "forward=k_front<%d, %d>;sort=k_csort_scan/scatter;reduce_item=k_seg_reduce<%d, %d, %d, false, true>;apply=%s",

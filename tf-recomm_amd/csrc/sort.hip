@@ -299,9 +299,9 @@ void launch_rsort_pass(const RSortArgs& a, int ncols, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
-// rsort, wide tiles: the same LSD pass for millions of keys (FM non-zeros: 8.4 M; AUC scores).  The 1024-key scatter above
-// writes 4 bytes at a time to 256 x ntiles different places - at 8.4 M keys that is 285 us per pass, four times what the bytes
-// cost.  Here a 1024-thread workgroup owns a tile of 4096 keys, ranks them itself (wave-private LDS counters + ballots: no
+// rsort, wide tiles: the same LSD pass from 65536 keys up (the big-table step's batches, FM non-zeros: 8.4 M, AUC scores).  The
+// 1024-key scatter above writes 4 bytes at a time to 256 x ntiles different places - at 8.4 M keys that is 285 us per pass, four
+// times what the bytes cost.  Here a 1024-thread workgroup owns a tile of 4096 keys, ranks them itself (wave-private LDS counters + ballots: no
 // lrank array to write and read back), stages key + value in LDS in digit order and writes every digit's run (16 keys on
 // average) as one contiguous piece.  Launches per pass: histogram, scan (the kernel above), scatter.
 constexpr int RW_TILE = 4096;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(1024) void k_rsortw_scatter(RSortArgs a) {
 
 bool rsortw_eligible(int64_t B) {
     static int64_t lo = -1;                              // TFR_RSORT_WIDE_MIN: smallest key count that takes the wide tiles
-    if (lo < 0) { const char* e = getenv("TFR_RSORT_WIDE_MIN"); lo = e ? atoll(e) : ((int64_t)1 << 20); }
+    if (lo < 0) { const char* e = getenv("TFR_RSORT_WIDE_MIN"); lo = e ? atoll(e) : 65536; }   // C3's 262144-key sort: 71 -> 66 us
     return B >= lo;
 }
 
