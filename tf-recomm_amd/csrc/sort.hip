@@ -341,7 +341,7 @@ __global__ __launch_bounds__(1024) void k_rsortw_scatter(RSortArgs a) {
     __shared__ int32_t dstart[256], gbase[256];
     __shared__ int32_t stage_k[RW_TILE], stage_v[RW_TILE];
     constexpr int PREF = 2048;
-    __shared__ int32_t pref[PREF];                       // (fused scan: [4][256] partial totals + [4][256] partial "before" counts)
+    __shared__ int32_t pref[PREF];
     __shared__ int32_t pw[16];
     __shared__ int32_t wsum[4];
     const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
@@ -360,22 +360,7 @@ __global__ __launch_bounds__(1024) void k_rsortw_scatter(RSortArgs a) {
     for (int q = tid; q < 16 * 256; q += 1024) (&wcnt[0][0])[q] = 0;
     // totals of the scan blocks in front of an entry of the histogram matrix: prefix them once per workgroup
     const int64_t nb = ((int64_t)256 * a.ntiles + a.chunk - 1) / a.chunk;
-    if (a.fuse_scan) {
-        // batch-sized sorts (<= 128 tiles): no scan launch - every workgroup reads the whole histogram matrix (<= 128 KB, L2)
-        // and derives its own offsets: thread (q, d) adds digit d's counts over a quarter of the tiles
-        const int d = tid & 255, q = tid >> 8;
-        const int per = (a.ntiles + 3) >> 2;
-        const int ta = q * per, tb = (ta + per < a.ntiles) ? ta + per : a.ntiles;
-        const int32_t* __restrict__ h = a.hist[col] + (size_t)d * a.ntiles;
-        int32_t tot = 0, bef = 0;
-        for (int t = ta; t < tb; ++t) {
-            const int32_t c = h[t];
-            tot += c;
-            bef += (t < tile) ? c : 0;
-        }
-        pref[q * 256 + d] = tot;
-        pref[1024 + q * 256 + d] = bef;
-    } else {
+    {
         const int32_t x0 = (2 * tid < nb && 2 * tid < PREF) ? a.blocktot[col][2 * tid] : 0;
         const int32_t x1 = (2 * tid + 1 < nb && 2 * tid + 1 < PREF) ? a.blocktot[col][2 * tid + 1] : 0;
         int32_t incl = x0 + x1;
@@ -411,30 +396,15 @@ __global__ __launch_bounds__(1024) void k_rsortw_scatter(RSortArgs a) {
         }
         if (lane == 63) wsum[wave] = incl;
         dstart[tid] = incl - tot;
-        if (a.fuse_scan) {
-            // keys of smaller digits in the whole column + this digit's keys in earlier tiles
-            const int32_t gtot = (pref[tid] + pref[256 + tid]) + (pref[512 + tid] + pref[768 + tid]);
-            const int32_t bef = (pref[1024 + tid] + pref[1280 + tid]) + (pref[1536 + tid] + pref[1792 + tid]);
-            int32_t gincl = gtot;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int32_t y = __shfl_up(gincl, o, 64);
-                if (lane >= o) gincl += y;
-            }
-            if (lane == 63) pw[wave] = gincl;            // pw[] is free again (the other branch's use ended before the barrier)
-            gbase[tid] = gincl - gtot + bef;              // + the digit totals of the waves in front: added below
-        } else {
-            const int64_t idx = (int64_t)tid * a.ntiles + tile;
-            const int qn = (int)(idx / a.chunk);
-            const int covered = qn < PREF ? qn : PREF - 1;
-            int32_t base = pref[covered];
-            for (int q = covered; q < qn; ++q) base += a.blocktot[col][q];
-            gbase[tid] = base + a.offs[col][idx];
-        }
+        const int64_t idx = (int64_t)tid * a.ntiles + tile;
+        const int qn = (int)(idx / a.chunk);
+        const int covered = qn < PREF ? qn : PREF - 1;
+        int32_t base = pref[covered];
+        for (int q = covered; q < qn; ++q) base += a.blocktot[col][q];
+        gbase[tid] = base + a.offs[col][idx];
     }
     __syncthreads();
     if (tid < 256) {
-        if (a.fuse_scan) for (int w = 0; w < wave; ++w) gbase[tid] += pw[w];
         int32_t run = dstart[tid];
         for (int w = 0; w < wave; ++w) run += wsum[w];
         dstart[tid] = run;
@@ -501,13 +471,8 @@ void launch_rsortw_pass(RSortArgs a, int ncols, hipStream_t s) {
         a.keys_in[0] = a.u_out; a.keys_in[1] = a.i_out;
         a.ids = nullptr;
     }
-    static int fuse = -1;                                // TFR_RSORT_FUSE_SCAN=0: A/B switch
-    if (fuse < 0) { const char* e = getenv("TFR_RSORT_FUSE_SCAN"); fuse = (e && e[0] == '0') ? 0 : 1; }
-    a.fuse_scan = (fuse && a.ntiles <= 128) ? 1 : 0;     // batch-sized: the scatter derives its offsets itself, two launches a pass
-    if (!a.fuse_scan) {
-        const int64_t total = (int64_t)256 * a.ntiles;
-        hipLaunchKernelGGL(k_rsort_scan, dim3((unsigned)((total + a.chunk - 1) / a.chunk), ncols), dim3(1024), 0, s, a);
-    }
+    const int64_t total = (int64_t)256 * a.ntiles;
+    hipLaunchKernelGGL(k_rsort_scan, dim3((unsigned)((total + a.chunk - 1) / a.chunk), ncols), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_rsortw_scatter, grid, dim3(1024), 0, s, a);
 }
 

@@ -296,7 +296,6 @@ struct RSortArgs {
     int32_t* lrank[2]; int32_t* hist[2]; int32_t* offs[2];   // hist/offs: [256 * ntiles], bin-major
     int32_t* blocktot[2];                                    // per scan block (chunk entries) totals
     int32_t shift, ntiles, chunk;                            // chunk: multiple of 1024, <= 16384
-    int32_t fuse_scan;                                       // wide tiles, <= 128 of them: no scan launch (set by launch_rsortw_pass)
     int64_t B;
     int32_t limit[2]; int32_t* err;                          // err != NULL: pass 0 flags keys outside [0, limit)
     // pass 0 may gather the batch itself (dataio.py:115-117 on the resident store): key = store[ids[k]].x / .y; the column-0

@@ -1,9 +1,9 @@
-# the wide-tile radix pass for batch-sized sorts: scan fused into the scatter (TFR_RSORT_FUSE_SCAN), one gpurun call
+# the wide-tile radix pass for batch-sized sorts too (TFR_RSORT_WIDE_MIN), one gpurun call
 set -e
 cd $GRAFT_REPO_ROOT
-for f in 1 0 1 0; do
-  echo "TFR_RSORT_FUSE_SCAN=$f"
-  TFR_RSORT_FUSE_SCAN=$f python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline --no-north-star 2>/dev/null | python -c "
+for lo in 65536 1048576 65536 1048576; do
+  echo "TFR_RSORT_WIDE_MIN=$lo"
+  TFR_RSORT_WIDE_MIN=$lo python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline --no-north-star 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 k=d['roofline']['kernels']
