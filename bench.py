@@ -632,7 +632,7 @@ def svd_single_gpu(key, wl, K, W, device, *, zipf=0.0, feeds=True, cpu=True, con
     return out
 
 
-def multi_gpu(args, rank, local_rank, world, force_dp):
+def multi_gpu(args, rank, local_rank, world, force_dp, saved_stdout):
     """One rank of the N>1 line.  Headline workload (c2: tables every GPU can hold) -> data parallel; tables at the scale
     sharding is meant for (c3 / c4) -> row-sharded.  The default line carries BOTH: the data-parallel headline and, as
     `sharded_c4`, BASELINE configs[3] row-sharded over the same GPUs (the north star's 1 -> 8 curve), plus the single-GPU
@@ -691,8 +691,13 @@ def multi_gpu(args, rank, local_rank, world, force_dp):
     res.update(extra)
     res["launcher"] = os.environ.get("TFR_BENCH_LAUNCHER", "torch.distributed.run or bench.py's own ranks")
     dist.barrier()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)                              # stdout is stdout again: the one line
+    os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(res), flush=True)
+    sys.stdout.flush()
+    os.dup2(2, 1)                                         # (and whatever the teardown prints goes to stderr)
     dist.destroy_process_group()
 
 
@@ -746,26 +751,28 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("TFR_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
-        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
+        # RCCL prints a version banner on stdout when a communicator comes up (the first one here, the side communicator of the
+        # row-sharded step later): stdout is pointed at stderr until the ONE JSON line is due (multi_gpu restores it)
         sys.stdout.flush()
-        saved = os.dup(1)
+        saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                t = torch.zeros(1, device=torch.device("cuda", local_rank))
-                dist.all_reduce(t)
-                dist.all_to_all_single(torch.empty_like(t.repeat(world)), t.repeat(world))
-                torch.cuda.synchronize()
-            else:
-                dist.init_process_group(backend)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            t = torch.zeros(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(t)
+            dist.all_to_all_single(torch.empty_like(t.repeat(world)), t.repeat(world))
+            torch.cuda.synchronize()
+        else:
+            dist.init_process_group(backend)
         print("bench.py rank %d/%d: communicator up (backend %s, world size %d, device %d)"
               % (rank, world, backend, dist.get_world_size(), local_rank), file=sys.stderr, flush=True)
 
+    if (world > 1 or force_dp) and (args.workload in ("als", "c5") or args.only_north_star):
+        sys.stdout.flush()                               # single-GPU workloads: nothing below brings up another communicator
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+        if rank != 0:
+            return
     if args.workload == "als":
         print(json.dumps(als_bench(local_rank)), flush=True)
         return
@@ -777,7 +784,7 @@ def main():
                                             I=args.ns_items, B=args.ns_batch, D=args.ns_dim, sequential=args.ns_sequential, zipf=args.ns_zipf)), flush=True)
         return
     if world > 1 or force_dp:
-        multi_gpu(args, rank, local_rank, world, force_dp)
+        multi_gpu(args, rank, local_rank, world, force_dp, saved_stdout)
         return
 
     wl = dict(WORKLOADS[args.workload])
