@@ -24,6 +24,22 @@ class OracleShard(object):
     def sync(self):
         pass
 
+    # ---- the two routed-batch sets of the product backend (tfr_shard_select / _presort): ShardedSvd prepares batch s+1 in the
+    #      other set while step s uses its own; here the "side stream" is just the call order
+    def select(self, which):
+        self._sets = getattr(self, "_sets", {})
+        if hasattr(self, "_r"):
+            self._sets[getattr(self, "_set", 0)] = self._r
+        self._set = int(which)
+        if self._set in self._sets:
+            self._r = self._sets[self._set]
+
+    def presort(self, req_recv):
+        pass
+
+    def on_stream(self, stream):
+        pass
+
     # ---- routing: the NumPy statement of csrc/shard.hip (what the device kernels must reproduce bit for bit)
     def route(self, u, i, r, rank, world, U, I, sample_cap, slot_cap):
         u, i, r = u.numpy().astype(np.int64), i.numpy().astype(np.int64), r.numpy().astype(np.float64)

@@ -199,3 +199,53 @@ def _dp_worker(rank, world, port, kw, U, I, D, B, steps):
 @pytest.mark.parametrize("kw", [dict(optimizer="adam", adam_mode="tf1"), dict(optimizer="sgd", lr=1e-2, reg=0.02)])
 def test_data_parallel_equals_one_global_step(kw):
     mp.spawn(_dp_worker, args=(2, _free_port(), kw, 40, 30, 5, 64, 3), nprocs=2, join=True)
+
+
+def _pipelined_worker(rank, world, port, kw, U, I, D, B, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfrecomm_amd import sharded, _lib as L
+        from tests.fake_shard_backend import OracleShard
+        rs = np.random.RandomState(17)
+        t = rand_tables(rs, U, I, D)
+        Ns = 3 * B + 5
+        su, si = dup_heavy_ids(rs, U, Ns), dup_heavy_ids(rs, I, Ns)
+        sr = rs.randint(1, 6, Ns).astype(np.float32)
+        rs_own = np.random.RandomState(2000 + rank)
+        batches = [torch.from_numpy(rs_own.randint(0, Ns, B)) for _ in range(steps)]
+        final = {}
+        for mode in ("pipelined", "plain"):
+            ref = make_oracle(U, I, D, t, **kw)
+            m = sharded.ShardedSvd(U, I, D, sharded.Comm(), lambda ur, ir, d: OracleShard(ur, ir, d, **kw))
+            m.set_tables_from_global(t["mu"], t["bu"], t["bi"], t["P"], t["Q"])
+            m.backend.set_store(torch.from_numpy(su), torch.from_numpy(si), torch.from_numpy(sr))
+            for s in range(steps):
+                # step 2 arrives without a prepared batch, step 3's prepared batch is thrown away (another batch is passed)
+                nxt = batches[s + 1] if (mode == "pipelined" and s + 1 < steps and s != 1) else None
+                cur = batches[s] if not (mode == "pipelined" and s == 3) else batches[s].clone()
+                logits, mine, scal = m.train_step_local_ids(cur, nxt)
+                allids = [None] * world
+                dist.all_gather_object(allids, batches[s].numpy())
+                union = np.concatenate(allids)
+                _, want_loss, want_reg = ref.train_step(su[union], si[union], sr[union])
+                assert abs(scal[0].item() - want_loss) <= 1e-10 * max(1.0, abs(want_loss)), (mode, s)
+                assert abs(scal[1].item() - want_reg) <= 1e-10 * max(1.0, abs(want_reg)), (mode, s)
+            got = m.gather_global_tables()
+            for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+                assert np.abs(np.asarray(got[tid], np.float64) - ref.tables()[tid]).max() <= 1e-9, (mode, tid)
+            final[mode] = {k: np.array(v) for k, v in got.items()}
+        for k in final["plain"]:
+            assert np.array_equal(final["plain"][k], final["pipelined"][k])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_front_end_of_the_next_batch_prepared_ahead(world):
+    """ShardedSvd.train_step_local_ids(ids, next_ids): bucket, exchanges and routing of the next batch into the backend's second
+    routed-batch set before the current step's updates - same trajectory as plain steps, also when a prepared batch is not the
+    one that arrives (exchange logic of the product, oracle-backed stand-in for the kernels)."""
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), dict(optimizer="adam", adam_mode="lazy"), 90, 70, 6, 120, 5),
+             nprocs=world, join=True)

@@ -385,7 +385,8 @@ class ShardedSvd(object):
         self._pre = None
         if pipelined and pre is not None and pre["ids"] == (ids.data_ptr(), ids.numel()):
             be.select(pre["set"])
-            torch.cuda.current_stream(self.device).wait_stream(self._side)     # the front end of this batch ran there
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).wait_stream(self._side)     # the front end of this batch ran there
             be._routed = pre["routed"]
             req_recv, cur = pre["req_recv"], pre["set"]
         else:
@@ -398,14 +399,19 @@ class ShardedSvd(object):
         hook = None
         if pipelined and next_ids is not None:
             def hook():
-                side = self._side_stream()
-                side.wait_stream(torch.cuda.current_stream(self.device))      # ids drawn / everything queued so far
-                with torch.cuda.stream(side):
+                if self.device.type == "cuda":
+                    side = self._side_stream()
+                    side.wait_stream(torch.cuda.current_stream(self.device))  # ids drawn / everything queued so far
+                    ctx = torch.cuda.stream(side)
+                else:                                    # CPU stand-in backend (tests): the same call order, no streams
+                    import contextlib
+                    side, ctx = None, contextlib.nullcontext()
+                with ctx:
                     be.on_stream(side)
                     be.select(cur ^ 1)
                     try:
                         rr = self._front_end(next_ids, c.side(), timed=False, presort=True)
-                        self._pre = dict(ids=(next_ids.data_ptr(), next_ids.numel()), set=cur ^ 1, req_recv=rr, routed=be._routed)
+                        self._pre = dict(ids=(next_ids.data_ptr(), next_ids.numel()), set=cur ^ 1, req_recv=rr, routed=getattr(be, "_routed", None))
                     finally:
                         be.select(cur)
                         be.on_stream(None)
