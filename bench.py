@@ -508,9 +508,9 @@ def svd_single_gpu(key, wl, K, W, device, *, zipf=0.0, feeds=True, cpu=True, con
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     m.train_steps_drawn(B, K)
-    torch.cuda.synchronize()                             # the contract's bracket: device-wide, so it covers the library's streams
+    m.sync()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    m.sync()                                             # (the deferred error check - a 4-byte copy - is not part of the step)
     ms_per_step = elapsed / K * 1e3
     value = K * B / elapsed
     sse, _, nval = m.eval_resident()
