@@ -80,7 +80,6 @@ struct tfr_model {
     // H2D copy, the kernels and one D2H copy instead of five pageable transfers
     int32_t* d_in = nullptr; int32_t* h_in = nullptr; float* h_out = nullptr; int64_t stage_cap = 0;
     int32_t* h_err = nullptr;                                // pinned landing place of the device error flag
-    bool err_mirrored = false;       // the last kernel enqueued was a step's K4, which left the flag in h_err[1] as well
     // look-ahead of the small-table step: the next batch's tile sort, published by the previous launch
     int4* srt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [parity][side] sorted records {u, i, r, pos}
     const int64_t* pf_ids = nullptr; int64_t pf_B = 0; int pf_par = 0; bool pf_valid = false;
@@ -307,14 +306,9 @@ static int ensure_step_out(tfr_model* m, int64_t nsteps) {
 }
 
 // read + clear the device error flag (stream must be idle or this call synchronises)
-static int check_device_error(tfr_model* m, bool mirrored = false) {
+static int check_device_error(tfr_model* m) {
     // the flag lands in pinned memory: a pageable destination turns the 4-byte copy into a staged, blocking one
     if (!m->h_err) HIPCHK(hipHostMalloc((void**)&m->h_err, 64, hipHostMallocDefault));
-    if (mirrored) {
-        // the last thing on the stream is a training step whose K4 wrote the flag to h_err[1] itself: drain and read it
-        HIPCHK(hipStreamSynchronize(m->stream));
-        if (m->h_err[1] == 0) return TFR_OK;
-    }
     *m->h_err = 0;
     HIPCHK(hipMemcpyAsync(m->h_err, m->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -335,8 +329,7 @@ static int check_device_error(tfr_model* m, bool mirrored = false) {
 
 #define MODEL_ENTER(m)                                                \
     if (!(m)) return fail(TFR_ERR_ARG, "null model");                 \
-    HIPCHK(hipSetDevice((m)->device));                                \
-    (m)->err_mirrored = false;        /* set again by a training step's K4; read by tfr_sync before it gets here */
+    HIPCHK(hipSetDevice((m)->device));
 
 // TFR_CALL_TRACE=1: host-side timestamps (us since the call's entry) of a multi-step call's phases on stderr
 struct CallTrace {
@@ -666,10 +659,9 @@ int tfr_get_stream(tfr_model* m, void** s) {
 }
 
 int tfr_sync(tfr_model* m) {
-    const bool mirrored = m && m->err_mirrored && m->h_err;
     MODEL_ENTER(m);
     CallTrace tr("sync");
-    const int rc = check_device_error(m, mirrored);
+    const int rc = check_device_error(m);
     tr.mark("main stream drained");
     return rc;
 }
@@ -1004,8 +996,6 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
     memset(&f, 0, sizeof(f));
     f.partials = m->partials; f.scalars = m->scalars; f.out = out3; f.out_err = out_err ? 1 : 0;
     f.mu = m->w[TFR_MU]; f.mu_m = m->m[TFR_MU]; f.mu_v = m->v[TFR_MU]; f.err = m->d_err;
-    if (!m->h_err && hipHostMalloc((void**)&m->h_err, 64, hipHostMallocDefault) != hipSuccess) m->h_err = nullptr;
-    f.err_host = m->h_err ? m->h_err + 1 : nullptr;      // K4 mirrors the flag: the sync after a step needs no copy
     f.update_mu = !((m->frozen >> TFR_MU) & 1); f.opt = adam ? 0 : 1;
     f.alpha = alpha; f.b1 = o.beta1; f.b2 = o.beta2; f.eps = o.eps; f.lr = o.lr;
     if (B > 0) {
@@ -1223,7 +1213,6 @@ static int run_train_step(tfr_model* m, const int32_t* du, const int32_t* di, co
         m->b2p *= o.beta2;
     }
     m->step += 1;
-    m->err_mirrored = f.err_host != nullptr;             // K4 was this step's last kernel on the stream
     return TFR_OK;
 }
 

@@ -62,7 +62,6 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
             }
             *a.mu = w;
         }
-        if (a.err_host) *a.err_host = *a.err;
         if (a.clear_partials) {
             float* pp = const_cast<float*>(a.partials);
             pp[0] = 0.f; pp[1] = 0.f; pp[2] = 0.f; pp[3] = 0.f;

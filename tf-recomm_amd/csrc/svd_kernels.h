@@ -95,8 +95,6 @@ struct FinArgs {
     float* mu; float* mu_m; float* mu_v; const int32_t* err;
     int32_t update_mu, opt, clear_partials;        // clear_partials: zero partials[0..3] after use
     int32_t out_err;                               // out[3] = the step's error flag (as a float)
-    int32_t* err_host;                             // optional pinned host word: K4 leaves the error flag there too, so the next
-                                                   // sync reads it without a device-to-host copy
     float alpha, b1, b2, eps, lr;
 };
 
