@@ -191,6 +191,8 @@ int tfr_forward_dev(tfr_model* m, const int32_t* d_user, const int32_t* d_item, 
                     float* d_logits);
 int tfr_train_step_dev(tfr_model* m, const int32_t* d_user, const int32_t* d_item,
                        const float* d_rate, int64_t batch, float* d_logits /* may be NULL */);
+/* (item_features: the fused big-table step keeps updated rows in an alternate table until another reader asks - this call, like
+ *  every reader, first brings them back; the pointer is current until the next big-table training step) */
 int tfr_table_devptr(tfr_model* m, int32_t which, void** ptr, int64_t* n);
 int tfr_set_stream(tfr_model* m, void* hip_stream);   /* NULL = the model's own stream; drains the stream in use first */
 /* the same without draining: for a caller that alternates between two streams and orders them itself with events (the
