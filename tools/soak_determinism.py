@@ -12,7 +12,7 @@ import bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 big = len(sys.argv) > 2 and sys.argv[2] == "big"     # radix-sort path with the look-ahead stream, lazy Adam
 if big:
-    U, I, D, B = 300000, 40000, 64, 50000
+    U, I, D, B = 300000, 40000, 64, 70000            # > 65536: the wide-tile radix pass
     train, _ = bench.synth_uniform(U, I, 3000000)
 else:
     U, I, D, B = 6040, 3952, 64, 10000
