@@ -2879,6 +2879,7 @@ struct tfr_fm {
     int64_t* d_indptr = nullptr;
     int32_t* d_indices = nullptr;
     float *d_data = nullptr, *d_y = nullptr, *d_out = nullptr, *s_rows = nullptr;
+    int4* ent = nullptr; int64_t ent_cap = 0;            // per non-zero {row, g x, lam - g x^2, -} of the training step
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -2960,13 +2961,20 @@ static int fm_train_core(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_in
         if ((rc = dmalloc(&f->s_rows, (size_t)n_rows * m->D))) return rc;
         f->s_cap = n_rows * m->D;
     }
+    if (nnz > f->ent_cap) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(f->ent);
+        f->ent = nullptr; f->ent_cap = 0;
+        if ((rc = dmalloc(&f->ent, (size_t)nnz))) return rc;
+        f->ent_cap = nnz;
+    }
     const float alpha = adam ? o.lr * sqrtf(1.f - m->b2p) / (1.f - m->b1p) : 0.f;
     hipStream_t s = m->stream;
     FmArgs a;
     memset(&a, 0, sizeof(a));
     a.V = m->w[TFR_P]; a.W = m->w[TFR_BU]; a.mu = m->w[TFR_MU];
     a.indptr = d_indptr; a.indices = d_indices; a.data = d_data; a.out = d_pred; a.err = m->d_err;
-    a.y = d_y; a.s_rows = f->s_rows; a.ent_row = m->d_i; a.ent_a = m->d_g; a.ent_b = m->d_r; a.partials = m->partials;
+    a.y = d_y; a.s_rows = f->s_rows; a.ent = f->ent; a.partials = m->partials;
     a.n_rows = n_rows; a.F = m->U; a.D = m->D; a.loss = o.loss; a.lam = o.reg;
     a.variant = fm_variant(m);
     const int grid = fm_grid(n_rows, m->G, true);
@@ -2990,7 +2998,7 @@ static int fm_train_core(tfr_fm* f, const int64_t* d_indptr, const int32_t* d_in
         memset(&r, 0, sizeof(r));
         r.err = m->d_err; r.B = nnz; r.D = m->D; r.side = 0; r.reg_bias = 1;
         r.lam = o.reg; r.alpha = alpha; r.b1 = o.beta1; r.b2 = o.beta2; r.eps = o.eps; r.lr = o.lr;
-        r.ks = m->ks_u; r.ps = m->ps_u; r.other = m->d_i; r.g = m->d_g; r.lam_arr = m->d_r;
+        r.ks = m->ks_u; r.ps = m->ps_u; r.ent = f->ent;
         r.own = m->w[TFR_P]; r.partner = f->s_rows; r.own_bias = m->w[TFR_BU];
         r.own_w = m->w[TFR_P]; r.m = m->m[TFR_P]; r.v = m->v[TFR_P];
         r.bias_w = m->w[TFR_BU]; r.bias_m = m->m[TFR_BU]; r.bias_v = m->v[TFR_BU];
@@ -3044,7 +3052,7 @@ int tfr_fm_destroy(tfr_fm* f) {
         (void)hipSetDevice(f->m->device);
         (void)hipStreamSynchronize(f->m->stream);
     }
-    dfree(f->d_indptr); dfree(f->d_indices); dfree(f->d_data); dfree(f->d_y); dfree(f->d_out); dfree(f->s_rows);
+    dfree(f->d_indptr); dfree(f->d_indices); dfree(f->d_data); dfree(f->d_y); dfree(f->d_out); dfree(f->s_rows); dfree(f->ent);
     if (f->ev0) (void)hipEventDestroy(f->ev0);
     if (f->ev1) (void)hipEventDestroy(f->ev1);
     tfr_destroy(f->m);

@@ -104,9 +104,8 @@ __global__ __launch_bounds__(256) void k_fm_forward(FmArgs a) {
             }
             for (int64_t p = lo + gl; p < hi; p += G) {       // per non-zero coefficients for the backward
                 const float x = a.data[p];
-                a.ent_row[p] = (int32_t)row;
-                a.ent_a[p] = g * x;
-                a.ent_b[p] = a.lam - g * x * x;
+                // one 16-byte record per non-zero {row, g x, lam - g x^2, -}: the backward reads one request per entry, not three
+                a.ent[p] = make_int4((int32_t)row, __float_as_int(g * x), __float_as_int(a.lam - g * x * x), 0);
             }
         }
     }

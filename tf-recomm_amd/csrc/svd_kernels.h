@@ -42,7 +42,8 @@ struct RedArgs {
     float* dense_rows; float* dense_bias;          // optional dense [rows,D] / [rows] gradient buffers
     int32_t dstride, dbstride;                     // their row / bias strides in floats (0 = D / 1): the packed exchange layout
     const float* rows_in; const float* bias_in;    // sharded owner side: pre-reduced gradient rows
-    const float* lam_arr;                          // optional per-entry coefficient of the own row (FM)
+    const int4* ent;                               // FM: {partner row, g x, lam - g x^2, -} per entry in one 16-byte record (one
+                                                   // request instead of the partner-id, g and coefficient gathers)
     float* own_copy_out;                           // optional [B,D]: the entry's pre-update own row, by batch position
     const float* partner_by_pos;                   // optional [B,D]: read the partner row from such a copy instead
     // two-table form of the fused big-table step (no pre-update copy): an item row lives in `own` or in `own_alt`, sel[row] says
@@ -147,7 +148,7 @@ struct FmArgs {
     const float* V; const float* W; const float* mu;
     const int64_t* indptr; const int32_t* indices; const float* data;
     float* out; int32_t* err;
-    const float* y; float* s_rows; int32_t* ent_row; float* ent_a; float* ent_b; float* partials;
+    const float* y; float* s_rows; int4* ent; float* partials;   // ent[nnz]: {row, g x, lam - g x^2, -} per non-zero (training)
     int64_t n_rows, F;
     int32_t D, loss;
     float lam;

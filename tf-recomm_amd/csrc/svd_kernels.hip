@@ -938,11 +938,23 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         }
     } else if (valid) {
         float gk = 0.f;
-        if constexpr (!FWD) gk = a.g[pos];
-        int32_t pid = a.partner_by_pos ? 0 : (a.osel_in ? a.osel_in[pos] : a.other[pos]);   // not needed when the partner row comes by position
+        int32_t pid;
+        float lam_e;
         const float* ptab = a.partner;
-        if (a.osel_in) { if (pid < 0) ptab = a.partner_alt; pid &= 0x7fffffff; }   // the table that still holds the pre-update row
-        const float lam_e = a.lam_arr ? a.lam_arr[pos] : a.lam;      // FM: lam - g x^2 per non-zero
+        bool have = false;
+        if constexpr (!FWD) {
+            if (a.ent) {                                             // FM: one 16-byte record per entry
+                const int4 e = a.ent[pos];
+                pid = e.x; gk = __int_as_float(e.y); lam_e = __int_as_float(e.z);
+                have = true;
+            }
+        }
+        if (!have) {
+            if constexpr (!FWD) gk = a.g[pos];
+            pid = a.partner_by_pos ? 0 : (a.osel_in ? a.osel_in[pos] : a.other[pos]);   // not needed when the partner row comes by position
+            if (a.osel_in) { if (pid < 0) ptab = a.partner_alt; pid &= 0x7fffffff; }   // the table that still holds the pre-update row
+            lam_e = a.lam;
+        }
         const Frag<VEC> x = a.partner_by_pos ? load_frag_h<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D, a.nt & 8)
                                              : load_frag_h<VEC>(ptab + (size_t)pid * (a.pstride ? a.pstride : D), d0, D, a.nt & 1);
         if (a.sel) {                                                 // two-table form: which table holds this row now
