@@ -195,6 +195,10 @@ def bench_entry(wl, K, W, rank, local_rank, world, train, val, workload_key="c2"
                 val_rmse=float(np.sqrt(sse / len(val[0]))),
                 roofline=dict(kernel="all_reduce (%s)" % ("gloo rehearsal: staged through host memory, times meaningless" if stage else "RCCL over xGMI"), bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
                               frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire, phases_us=phases,
+                              # per GPU against HBM (SURVEY 8(d), tf1 Adam: 8D+56 per rating + the dense term 24 (U+I)(D+1) per step)
+                              hbm_per_gpu=dict(algorithmic_bytes_per_step=B * (8 * D + 56) + 24 * (U + I) * (D + 1),
+                                               achieved_GBps=(B * (8 * D + 56) + 24 * (U + I) * (D + 1)) / step_s / 1e9, peak=8000.0,
+                                               frac=(B * (8 * D + 56) + 24 * (U + I) * (D + 1)) / step_s / 1e9 / 8000.0),
                               note="bytes each rank sends per step, 2 (N-1)/N x the %.1f MB gradient buffer, over the whole step time; the "
                                    "2.6 MB model makes this step latency-bound (collective launch + a few link hops), not bandwidth-bound; "
                                    "with world=1 nothing crosses a link" % (nbytes / 1e6)),

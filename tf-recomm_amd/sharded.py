@@ -637,6 +637,10 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
                 roofline=dict(kernel="all_to_all (%s)" % ("gloo rehearsal: staged through host memory, times meaningless" if comm.stage else "RCCL over xGMI"), bound="xgmi", achieved=xgmi, peak=XGMI_EGRESS_GBS, unit="GB/s",
                               frac=xgmi / XGMI_EGRESS_GBS, traffic=wire, algorithmic_bytes_per_step=wire,
                               exchange_us_per_step=exch_us, phases_us=phases, host_enqueue_us_per_step=host_enqueue_s / K * 1e6,
+                              # north_star: "ratings/sec and achieved fraction of the HBM roofline" per GPU - SURVEY 8(d)'s 56D+104 bytes per
+                              # rating of the lazy-Adam step x this GPU's B ratings per step, over the step time, against 8 TB/s
+                              hbm_per_gpu=dict(algorithmic_bytes_per_step=B * (56 * D + 104), achieved_GBps=B * (56 * D + 104) / step_s / 1e9,
+                                               peak=8000.0, frac=B * (56 * D + 104) / step_s / 1e9 / 8000.0),
                               note="egress bytes per rank and step (fixed-capacity slots: %d of them to each of %d peers, %d B each way per slot) "
                                    "over the whole step time; 7 links x 153 GB/s per GPU; with world=1 nothing crosses a link"
                                    % (slot_cap, world - 1, 2 * packed_stride(D) * 4 + 4)),
