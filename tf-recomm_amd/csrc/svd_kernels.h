@@ -44,7 +44,6 @@ struct RedArgs {
     const float* rows_in; const float* bias_in;    // sharded owner side: pre-reduced gradient rows
     const int4* ent;                               // FM: {partner row, g x, lam - g x^2, -} per entry in one 16-byte record (one
                                                    // request instead of the partner-id, g and coefficient gathers)
-    int32_t ent_sorted;                            // ... already in sorted order (indexed by j, not by ps[j]): one dependent hop less
     float* own_copy_out;                           // optional [B,D]: the entry's pre-update own row, by batch position
     const float* partner_by_pos;                   // optional [B,D]: read the partner row from such a copy instead
     // two-table form of the fused big-table step (no pre-update copy): an item row lives in `own` or in `own_alt`, sel[row] says
@@ -290,7 +289,6 @@ void launch_mt_draw(uint32_t* d_state, int64_t* d_out, int64_t need, uint32_t rn
 constexpr int CSORT_TILE = 1024;
 constexpr int CSORT_MAX_BINS = 16384;          // 64 KB of LDS counters
 void launch_settle_alt(float* main_t, const float* alt_t, int32_t* sel, int64_t rows, int D, hipStream_t s);
-void launch_permute_rec(const int4* in, const int32_t* ps, int4* out, int64_t n, hipStream_t s);   // out[j] = in[ps[j]]
 bool csort_eligible(int64_t B, int bits_u, int bits_i);
 void launch_csort(const CSortArgs& a, const FinArgs* fin, hipStream_t s);   // fin: run K4 in the scan launch
 // LSD radix sort pass (8-bit digit at `shift`) over up to two key columns

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         bool have = false;
         if constexpr (!FWD) {
             if (a.ent) {                                             // FM: one 16-byte record per entry
-                const int4 e = a.ent[a.ent_sorted ? j : (int64_t)pos];
+                const int4 e = a.ent[pos];
                 pid = e.x; gk = __int_as_float(e.y); lam_e = __int_as_float(e.z);
                 have = true;
                 // FM, factored: sum_k (g_k x_k + lam_k o) = sum_k g_k x_k + (sum_k lam_k) o, so only the group that adds a piece
@@ -1861,26 +1861,6 @@ __global__ __launch_bounds__(256) void k_settle_alt(float* __restrict__ main_t, 
         for (int d = lane; d < D; d += 64) main_t[(size_t)r * D + d] = alt_t[(size_t)r * D + d];
         if (lane == 0) sel[r] = 0;
     }
-}
-
-// out[j] = in[ps[j]]: per-entry records brought into sorted order once, so that the reduce reads them with the sorted keys
-// instead of through ps[j] (one dependent memory hop less in a kernel whose blocks live for as long as their hops take)
-__global__ __launch_bounds__(256) void k_permute_rec(const int4* __restrict__ in, const int32_t* __restrict__ ps, int4* __restrict__ out, int64_t n) {
-    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
-    for (int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; j0 < n; j0 += stride) {
-        int4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = (j0 + q < n) ? in[ps[j0 + q]] : make_int4(0, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (j0 + q < n) out[j0 + q] = v[q];
-    }
-}
-
-void launch_permute_rec(const int4* in, const int32_t* ps, int4* out, int64_t n, hipStream_t s) {
-    int64_t nb = (n + 1023) / 1024;
-    if (nb > 16384) nb = 16384;
-    if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(k_permute_rec, dim3((int)nb), dim3(256), 0, s, in, ps, out, n);
 }
 
 void launch_settle_alt(float* main_t, const float* alt_t, int32_t* sel, int64_t rows, int D, hipStream_t s) {
