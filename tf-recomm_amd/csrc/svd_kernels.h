@@ -201,8 +201,7 @@ constexpr size_t tile_step_dyn_lds(int G, int VEC, int EPG, int nbmax) {
     return (size_t)nbmax * 4 > (size_t)2 * EPG * 16 * G * VEC * 4 ? (size_t)nbmax * 4 : (size_t)2 * EPG * 16 * G * VEC * 4;
 }
 constexpr size_t seg_reduce_static_lds(int G, int VEC, bool fwd) {
-    return (size_t)1024 * VEC * 4 + (size_t)2 * (1024 / G) * 4 +
-           (fwd ? (size_t)(2 * (1024 / G) + 1024) * 4 + 16 * 3 * 4 + 4 : 4 + (size_t)(1024 / G) * 4);   // + lds_lam
+    return (size_t)1024 * VEC * 4 + (size_t)2 * (1024 / G) * 4 + (fwd ? (size_t)(2 * (1024 / G) + 1024) * 4 + 16 * 3 * 4 : 4);
 }
 int tile_step_epg(int ntiles, int G, int VEC);       // pieces per block k_tile_step will use (grid = ntiles * G / epg per side)
 

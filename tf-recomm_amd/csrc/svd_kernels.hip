@@ -883,8 +883,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     __shared__ float lds_gb[EPB];
     __shared__ int32_t lds_key[EPB];
     __shared__ float lds_stage[FWD ? 2 * EPB + 1024 : 1];
-    __shared__ float lds_lam[FWD ? 1 : EPB];             // FM (a.ent): the entry's own-row coefficient, see "factored" below
-    static_assert(sizeof(lds_t) + sizeof(lds_gb) + sizeof(lds_key) + sizeof(lds_stage) + sizeof(lds_lam) + (FWD ? 16 * 3 * 4 : 0) == seg_reduce_static_lds(G, VEC, FWD),
+    static_assert(sizeof(lds_t) + sizeof(lds_gb) + sizeof(lds_key) + sizeof(lds_stage) + (FWD ? 16 * 3 * 4 : 0) == seg_reduce_static_lds(G, VEC, FWD),
                   "seg_reduce_static_lds() is out of date");
     const RedArgs& a = pr.a[blockIdx.y];
     const int32_t err = *a.err;
@@ -918,8 +917,6 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 
     Frag<VEC> o, t, mrow, vrow;
     float ob = 0.f, tb = 0.f, mb = 0.f, vb = 0.f;
-    float lam_e = 0.f;
-    bool fm = false;                                     // FM entry: the own-row term is added once per piece (factored)
     int32_t cur = 0;                                     // two-table form: the table this entry's own row is in
     float facc[3] = {0.f, 0.f, 0.f};                     // FWD: this lane's {loss, reg, g} share
 #pragma unroll
@@ -942,6 +939,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     } else if (valid) {
         float gk = 0.f;
         int32_t pid;
+        float lam_e;
         const float* ptab = a.partner;
         bool have = false;
         if constexpr (!FWD) {
@@ -949,10 +947,6 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
                 const int4 e = a.ent[pos];
                 pid = e.x; gk = __int_as_float(e.y); lam_e = __int_as_float(e.z);
                 have = true;
-                // FM, factored: sum_k (g_k x_k + lam_k o) = sum_k g_k x_k + (sum_k lam_k) o, so only the group that adds a piece
-                // up needs the own row (and bias) - a feature's run is ~8 entries long, and the hardware does not merge their
-                // simultaneous misses on the same row (counters: 5.3 read requests per entry, 3 of them the own row + bias)
-                fm = true;
             }
         }
         if (!have) {
@@ -967,10 +961,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             cur = a.sel[row];
             if (gl == 0) a.osel_out[pos] = row | (cur << 31);
         }
-        if (!fm || pstart) {
-            o = load_frag_h<VEC>((cur ? a.own_alt : a.own) + ooff, d0, D, a.nt & 2);
-            ob = a.own_bias[oboff];
-        }
+        o = load_frag_h<VEC>((cur ? a.own_alt : a.own) + ooff, d0, D, a.nt & 2);
+        ob = a.own_bias[oboff];
         if constexpr (RMODE == RMODE_ADAM) {
             if (head) {
                 mrow = load_frag_h<VEC>(a.m + roff, d0, D, a.nt & 2);
@@ -1018,15 +1010,14 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             float xv = x.v[q];
             if (a.side == 0) { if (a.item_abs) xv = fabsf(xv); }
             else if (a.item_abs) xv = xv * ((o.v[q] > 0.f) ? 1.f : ((o.v[q] < 0.f) ? -1.f : 0.f));
-            t.v[q] = fm ? gk * xv : gk * xv + lam_e * o.v[q];
+            t.v[q] = gk * xv + lam_e * o.v[q];
         }
-        tb = (a.reg_bias && !fm) ? (gk + a.lam * ob) : gk;
+        tb = a.reg_bias ? (gk + a.lam * ob) : gk;
     }
     // contributions to LDS ([entry][G*VEC], a lane's VEC floats contiguous)
 #pragma unroll
     for (int q = 0; q < VEC; ++q) lds_t[(grp * G + gl) * VEC + q] = t.v[q];
     if (gl == 0) { lds_gb[grp] = tb; lds_key[grp] = row; }
-    if constexpr (!FWD) { if (a.ent && gl == 0) lds_lam[grp] = lam_e; }
     if constexpr (FWD) {                                 // has the barrier
         if (a.stage_sum) block_sum_pieces<G, 1>(facc, lds_stage, a.partials + (size_t)blockIdx.x * 4);
         else block_sum_store<3, 16>(facc, a.partials + (size_t)blockIdx.x * 4);
@@ -1035,11 +1026,10 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 
     Frag<VEC> acc = t;
     float gb = tb;
-    float lsum = lam_e;                                  // FM: sum of the piece's own-row coefficients (added once, below)
     int e = grp + 1;
     for (;;) {                                           // four LDS entries per round trip, added in order
         bool same[4];
-        float xv[4][VEC], xb[4], xl[4];
+        float xv[4][VEC], xb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ee = (e + q < EPB) ? e + q : grp;   // in-bounds address; masked by same[]
@@ -1047,7 +1037,6 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 #pragma unroll
             for (int c2 = 0; c2 < VEC; ++c2) xv[q][c2] = lds_t[(ee * G + gl) * VEC + c2];
             xb[q] = lds_gb[ee];
-            if constexpr (!FWD) xl[q] = a.ent ? lds_lam[ee] : 0.f; else xl[q] = 0.f;
         }
         bool go = true;
         int taken = 0;
@@ -1058,17 +1047,11 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
 #pragma unroll
                 for (int c2 = 0; c2 < VEC; ++c2) acc.v[c2] += xv[q][c2];
                 gb += xb[q];
-                lsum += xl[q];
                 ++taken;
             }
         }
         e += taken;
         if (!go) break;
-    }
-    if (fm) {                                            // the piece's own-row term: (sum of lam_k) o, and for the bias lam * n * W[f]
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) acc.v[q] += lsum * o.v[q];
-        if (a.reg_bias) gb += a.lam * (float)(e - grp) * ob;
     }
     bool cont = false;                                   // does the run continue in the next block?
     if (e == EPB && blk0 + EPB < Bn && !(a.tile && ((blk0 + EPB) % a.tile) == 0)) cont = (a.ks[blk0 + EPB] == row);
