@@ -125,32 +125,38 @@ __global__ __launch_bounds__(256) void k_als_fit(AlsFitArgs a) {
         }
         if (tid < d) bvec[tid] = accb;
         __syncthreads();
-        // Cholesky A = L L^T, in place (lower triangle), column by column
-        for (int j = 0; j < d; ++j) {
-            if (tid == 0) {
-                double s = A[j][j];
-                for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
-                A[j][j] = sqrt(s);
+        // Cholesky A = L L^T (in place, lower triangle) and the two triangular solves, by ONE wave: lane r owns row r, a column
+        // step is j LDS reads of row j (broadcast) and of the lane's own row - no block barrier (a wave's LDS accesses are made
+        // in program order; volatile keeps the compiler from moving a read of another lane's element over the write it follows).
+        // The block-wide version (thread 0 alone on the diagonal and in the substitutions, a barrier pair per column) cost
+        // ~50 us per entity, most of the sweep.  Same operations in the same order per element.
+        if (tid < 64) {
+            const int r = tid;
+            volatile double (*L)[ALS_MAXD + 1] = A;
+            for (int j = 0; j < d; ++j) {
+                double s = 0.0;
+                if (r >= j && r < d) {
+                    s = L[r][j];
+                    for (int k = 0; k < j; ++k) s -= L[r][k] * L[j][k];
+                }
+                const double piv = sqrt(__shfl(s, j, 64));
+                if (r == j) L[j][j] = piv;
+                else if (r > j && r < d) L[r][j] = s / piv;
             }
-            __syncthreads();
-            if (tid > j && tid < d) {
-                double s = A[tid][j];
-                for (int k = 0; k < j; ++k) s -= A[tid][k] * A[j][k];
-                A[tid][j] = s / A[j][j];
+            // L y = b, column by column: lane i finishes y_i, the lanes below take it off their right-hand sides
+            double y = (r < d) ? bvec[r] : 0.0;
+            for (int i = 0; i < d; ++i) {
+                const double yi = __shfl(y / ((r == i) ? L[i][i] : 1.0), i, 64);
+                if (r == i) y = yi;
+                else if (r > i && r < d) y -= L[r][i] * yi;
             }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            for (int i = 0; i < d; ++i) {                 // L y = b
-                double s = bvec[i];
-                for (int k = 0; k < i; ++k) s -= A[i][k] * xvec[k];
-                xvec[i] = s / A[i][i];
+            // L^T x = y, from the last column up: column i of L^T is row i of L
+            for (int i = d - 1; i >= 0; --i) {
+                const double xi = __shfl(y / ((r == i) ? L[i][i] : 1.0), i, 64);
+                if (r == i) y = xi;
+                else if (r < i) y -= L[i][r] * xi;
             }
-            for (int i = d - 1; i >= 0; --i) {            // L^T x = y
-                double s = xvec[i];
-                for (int k = i + 1; k < d; ++k) s -= A[k][i] * xvec[k];
-                xvec[i] = s / A[i][i];
-            }
+            if (r < d) xvec[r] = y;
         }
         __syncthreads();
         if (tid < d) a.own[(size_t)idx * d + tid] = xvec[tid];
