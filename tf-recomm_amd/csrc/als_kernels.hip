@@ -5,7 +5,7 @@
 //   Inside one half-sweep every entity only reads the OTHER side's tables, so all users (then all
 //   works) are independent: one 256-thread block per entity builds the d x d normal equations from
 //   32-row tiles staged in LDS, factors them (Cholesky; A is SPD because of the lambda*N*I term) and
-//   back-substitutes.  Lists longer than 2048 ratings are cut into chunks: k_als_partial builds each chunk's
+//   back-substitutes.  Lists longer than 512 ratings are cut into chunks: k_als_partial builds each chunk's
 //   partial sums in its own block, the entity's block adds them in list order.  Fixed summation order ->
 //   deterministic.  d <= 32.
 //   predict (als3.py:110-113) at explicit (user, work) pairs - the dense U V^T is never formed.
@@ -367,7 +367,7 @@ int tfr_als_load(tfr_als* m, const int64_t* user_ids, const int64_t* work_ids, c
     m->n = n; m->n_users = (int64_t)lu.size(); m->n_works = (int64_t)lw.size();
     // long lists (a blockbuster item can hold a few per cent of all ratings) would leave one block working
     // long after the rest of the sweep has finished: cut them into chunks of CH ratings
-    int64_t CH = 2048;
+    int64_t CH = 512;                                     // A/B in one call: 2048 1.33 ms per iteration, 1024 1.18, 512 1.12, 256 1.16, 128 1.38
     if (const char* e = getenv("TFR_ALS_CHUNK")) { const long v = atol(e); if (v >= ALS_TILE) CH = (v / ALS_TILE) * ALS_TILE; }
     size_t max_chunks = 0;
     for (int z = 0; z < 2; ++z) {
