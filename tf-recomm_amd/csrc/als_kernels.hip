@@ -42,18 +42,13 @@ struct AlsFitArgs {
 __device__ __forceinline__ void als_accumulate(const AlsFitArgs& a, int64_t lo, int64_t hi, double b0, double (&acc)[4], double& accb,
                                                double (*rows)[ALS_MAXD + 1], double* coef) {
     const int tid = threadIdx.x, d = a.d;
-    __shared__ int32_t tile_ids[2][ALS_TILE];             // the tile's partner ids, fetched one tile ahead: the row gathers below then
-    if (tid < ALS_TILE && lo + tid < hi) tile_ids[0][tid] = a.ids[lo + tid];     // start at once instead of behind an id load each
-    __syncthreads();
-    int par = 0;
-    for (int64_t s = lo; s < hi; s += ALS_TILE, par ^= 1) {
+    for (int64_t s = lo; s < hi; s += ALS_TILE) {
         const int nk = (int)((hi - s < ALS_TILE) ? hi - s : ALS_TILE);
         for (int t = tid; t < nk * d; t += 256) {
             const int k = t / d, c = t % d;
-            rows[k][c] = a.other[(size_t)tile_ids[par][k] * d + c];
+            rows[k][c] = a.other[(size_t)a.ids[s + k] * d + c];
         }
-        if (tid < nk) coef[tid] = a.vals[s + tid] - a.w_other[tile_ids[par][tid]] - b0;
-        if (tid >= 64 && tid < 64 + ALS_TILE && s + ALS_TILE + (tid - 64) < hi) tile_ids[par ^ 1][tid - 64] = a.ids[s + ALS_TILE + (tid - 64)];
+        if (tid < nk) coef[tid] = a.vals[s + tid] - a.w_other[a.ids[s + tid]] - b0;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
