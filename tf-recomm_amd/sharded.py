@@ -537,7 +537,10 @@ def bench_entry(wl, K, W, rank, local_rank, world, workload_key="c3"):
     (rank 0 prints)."""
     import torch.cuda
     dev = torch.device("cuda", local_rank)
-    comm = Comm(side_group=dist.new_group())             # the next batch's small exchanges get a communicator of their own
+    # TFR_SHARD_SIDE_COMM=1: the next batch's small exchanges on a communicator of their own (they then never queue between this
+    # step's row exchanges).  Default off: one communicator runs every collective of a rank in issue order, which cannot
+    # deadlock whatever the placement of the RCCL kernels; the measured difference at world 1 is nil (DESIGN 6)
+    comm = Comm(side_group=dist.new_group() if os.environ.get("TFR_SHARD_SIDE_COMM") else None)
     U, I, D, B = wl["U"], wl["I"], wl["D"], wl["B"]
     Bg = B * world
     opts = dict(optimizer="adam", adam_mode=wl["adam_mode"], lr=wl["lr"], reg=wl["reg"])
