@@ -396,9 +396,14 @@ class ShardedSvd(object):
             # (with a second routed-batch set every step pre-sorts: the step phases then never touch the sort scratch, which a
             # front end running beside them on the side stream uses)
             req_recv = self._front_end(ids, c, timed=True, presort=pipelined)
-        hook = None
+        hook_a = hook_b = None
         if pipelined and next_ids is not None:
-            def hook():
+            # The next batch's front end in two parts, so that on ONE communicator (collectives run in issue order) neither of this
+            # step's row-sized exchanges queues behind a small one that still waits for side-stream kernels: bucket + sample
+            # exchange + routing once this step's rows are on their way; request exchange + sorts once its gradient rows are.
+            state = {}
+
+            def on_side(fn):
                 if self.device.type == "cuda":
                     side = self._side_stream()
                     side.wait_stream(torch.cuda.current_stream(self.device))  # ids drawn / everything queued so far
@@ -410,14 +415,22 @@ class ShardedSvd(object):
                     be.on_stream(side)
                     be.select(cur ^ 1)
                     try:
-                        rr = self._front_end(next_ids, c.side(), timed=False, presort=True)
-                        self._pre = dict(ids=(next_ids.data_ptr(), next_ids.numel()), set=cur ^ 1, req_recv=rr, routed=getattr(be, "_routed", None))
+                        fn()
                     finally:
                         be.select(cur)
                         be.on_stream(None)
                 be._routed = self._routed_now
+
+            def hook_a():
+                on_side(lambda: state.update(req=self._front_end_a(next_ids, c.side(), timed=False), routed=getattr(be, "_routed", None)))
+
+            def hook_b():
+                def second():
+                    rr = self._front_end_b(state["req"], c.side(), timed=False, presort=True)
+                    self._pre = dict(ids=(next_ids.data_ptr(), next_ids.numel()), set=cur ^ 1, req_recv=rr, routed=state["routed"])
+                on_side(second)
         self._routed_now = getattr(be, "_routed", None)
-        return self._exchange_and_update(None, req_recv=req_recv, after_rows=hook)
+        return self._exchange_and_update(None, req_recv=req_recv, after_rows=hook_a, after_grads_start=hook_b)
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -426,6 +439,10 @@ class ShardedSvd(object):
 
     def _front_end(self, ids, c, timed, presort=False):
         """bucket -> sample exchange -> routing -> request exchange (-> the step's sorts): the integer part of a step"""
+        return self._front_end_b(self._front_end_a(ids, c, timed), c, timed, presort)
+
+    def _front_end_a(self, ids, c, timed):
+        """first half: bucket -> sample exchange -> routing; returns the request slots"""
         be = self.backend
         pair_cap = self.pair_capacity(ids.numel())
         sample_cap, slot_cap = self.capacities(ids.numel() * self.world)
@@ -439,6 +456,11 @@ class ShardedSvd(object):
         t = self._phase("route") if timed else None
         req = be.route_recs(recv, self.rank, self.world, self.U, self.I, sample_cap, slot_cap)
         self._end(t)
+        return req
+
+    def _front_end_b(self, req, c, timed, presort):
+        """second half: request exchange (-> the step's sorts); returns the requests received as an owner"""
+        be = self.backend
         t = self._phase("all_to_all ids") if timed else None
         req_recv = c.all_to_all(req, self._named_buf("req_recv", req))         # slots asked of me, by requester
         self._end(t)
@@ -458,7 +480,7 @@ class ShardedSvd(object):
             b = bufs[key] = torch.empty_like(like)
         return b
 
-    def _exchange_and_update(self, req, req_recv=None, after_rows=None):
+    def _exchange_and_update(self, req, req_recv=None, after_rows=None, after_grads_start=None):
         c, be = self.comm, self.backend
         if req_recv is None:
             t = self._phase("all_to_all ids")
@@ -480,6 +502,8 @@ class ShardedSvd(object):
             self._end(t)
             t = self._phase("all_to_all grads (start) + reduce_users")
             grad_recv, work = c.all_to_all_start(grad, self._recv_buf(grad))   # by requester: rank order = fixed add order
+            if after_grads_start is not None:
+                after_grads_start()                                            # second part of the next batch's front end
             be.reduce_users(item_rows)
             self._end(t)
             t = self._phase("all_to_all grads (wait)")
@@ -493,6 +517,8 @@ class ShardedSvd(object):
             t = self._phase("all_to_all grads")
             grad_recv = c.all_to_all(grad)                                 # by requester: rank order = fixed add order
             self._end(t)
+            if after_grads_start is not None:
+                after_grads_start()
         t = self._phase("apply_items")
         be.apply_items(req_recv, grad_recv)
         self._end(t)
