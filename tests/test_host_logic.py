@@ -118,3 +118,23 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert "started 2 ranks" in err, err
     assert "rank 0/2 needs an MI355X" in err and "rank 1/2 needs an MI355X" in err, err
     assert p.returncode != 0 and p.stdout.decode().strip() == ""
+
+
+def test_bench_finds_the_committed_counter_summaries():
+    """bench.py reads `roofline.traffic` from profiles/<round>_pmc_<workload>.csv: every kernel a BENCH roofline block names must be
+    in the committed summaries of the current round (a renamed template instantiation or a missing file would silently give null)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    r = bench.PROFILE_ROUND
+    for fname, kern in ((r + "_pmc_c2.csv", "k_tile_step<16, 4, 2>"), (r + "_pmc_c2.csv", "k_dense_tiles<16, 4, false, 10>"),
+                        (r + "_pmc_c3.csv", "k_seg_reduce<32, 4, 1, true, true>"), (r + "_pmc_c3.csv", "k_seg_reduce<32, 4, 1, false, true>"),
+                        (r + "_pmc_c4.csv", "k_seg_reduce<32, 4, 1, true, true>"), (r + "_pmc_c5.csv", "k_fm_forward<16, 4, false, true>"),
+                        (r + "_pmc_forward_uniform.csv", "k_forward<32, 4, 0, 4, true>"), (r + "_pmc_forward_zipf.csv", "k_forward<32, 4, 0, 4, true>"),
+                        (r + "_pmc_forward_8x_batch.csv", "k_forward<32, 4, 0, 4, true>")):
+        t = bench.profiled_traffic(fname, kern)
+        assert t is not None and t > 1e6, (fname, kern, t)
+    # the forward's counter traffic: 2.61 M read requests of 128 B per 262144-rating launch (+ ~1 MB written)
+    assert abs(bench.profiled_traffic(r + "_pmc_forward_uniform.csv", "k_forward<32, 4, 0, 4, true>") - 335.5e6) < 5e6
