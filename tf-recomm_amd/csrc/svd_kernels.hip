@@ -53,6 +53,23 @@ __device__ __forceinline__ void store_frag(float* __restrict__ row, int d0, int 
     }
 }
 
+// a lane's VEC floats of a row known to be G * VEC wide: no `d0 < D` guard, so the loaded registers are not merged with a
+// zero-initialised copy afterwards (that merge is a register move behind a full wait for the load)
+template <int VEC, bool NT>
+__device__ __forceinline__ Frag<VEC> load_full(const float* __restrict__ p) {
+    Frag<VEC> f;
+    if constexpr (VEC == 4) {
+        floatx4 t;
+        if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(p));
+        else t = *reinterpret_cast<const floatx4*>(p);
+        f.v[0] = t.x; f.v[1] = t.y; f.v[2] = t.z; f.v[3] = t.w;
+    } else {
+        if constexpr (NT) f.v[0] = __builtin_nontemporal_load(p);
+        else f.v[0] = *p;
+    }
+    return f;
+}
+
 // cache-policy experiments on the big-table step (RedArgs::nt bits; A/B by TFR_NT): runtime-selected hints
 template <int VEC>
 __device__ __forceinline__ Frag<VEC> load_frag_h(const float* __restrict__ row, int d0, int D, bool nt) {
@@ -876,7 +893,11 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 //     Both sides run fused: the item side goes first and copies each entry's pre-update Q row
 //     to own_copy_out[pos]; the user side then takes its partner rows from that copy
 //     (partner_by_pos), so neither side sees a row the other has already moved.
-template <int G, int VEC, int RMODE, bool FWD = false, bool LEAN = true>
+//     FAST (the two-table big-table step, fused forward on the item side; launch_seg_reduce checks the conditions): the same
+//     arithmetic with the loads issued in three dependent rounds instead of eight - {sorted id, neighbour, position}, then
+//     everything the row id / position alone address (partner id, table selector, rating or g, the m / v rows, biases), then the
+//     partner and own rows - so a block spends one HBM latency on its rows, not three in a row.
+template <int G, int VEC, int RMODE, bool FWD = false, bool LEAN = true, bool FAST = false>
 __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     constexpr int EPB = 1024 / G;
     __shared__ float lds_t[EPB * G * VEC];
@@ -896,10 +917,11 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     const int64_t Bn = a.dB ? (int64_t)*a.dB : a.B;      // row-sharded step: the entry count lives on the device
     const bool valid = j < Bn;
     int32_t row = -1, prev = -2, pos = 0;
-    if (valid) {
+    if (valid) {                                         // three independent loads, one round trip
         row = a.ks[j];
-        prev = (j > 0) ? a.ks[j - 1] : -2;
         pos = a.ps[j];
+        prev = a.ks[j > 0 ? j - 1 : 0];
+        if (j == 0) prev = -2;
     }
     if (err || blk0 >= Bn) {                 // an out-of-range id voids the whole step (block-uniform)
         // a grid sized for a capacity (row-sharded step: the entry count lives on the device): the blocks past the
@@ -907,6 +929,9 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         if constexpr (FWD) { if (!err && a.dB && threadIdx.x < 4) a.partials[(size_t)blockIdx.x * 4 + threadIdx.x] = 0.f; }
         return;
     }
+    // the key the next block starts with (does this block's last run continue there?): block-uniform, asked for now and not
+    // after the walk, where it was one more dependent round trip at the end of every block
+    const int32_t nextkey = (blk0 + EPB < Bn) ? a.ks[blk0 + EPB] : -3;
     // tile mode: the sorted order is per 1024-entry tile, so a run also starts at every tile start
     const bool head = valid && (prev != row || (a.tile && (j % a.tile) == 0));
     const bool pstart = valid && (head || grp == 0);
@@ -921,7 +946,52 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     float facc[3] = {0.f, 0.f, 0.f};                     // FWD: this lane's {loss, reg, g} share
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { o.v[q] = 0.f; t.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
-    if (valid && a.rows_in) {
+    bool owner_side = false;
+    if constexpr (!FAST) owner_side = valid && a.rows_in;
+    // FAST: the loads, branch-free (lanes past the entries and non-head lanes read row / position 0 and drop the result) and in
+    // three rounds.  `cond ? a.p : a.q` on two kernel-argument pointers would be compiled into a VECTOR load of the pointer from
+    // the argument block at a selected offset - a dependent round trip of its own; the table is chosen by an offset instead.
+    Frag<VEC> xf;
+    float pbf = 0.f, rvf = 0.f, gkf = 0.f;
+    int32_t pidf = 0;
+    if constexpr (FAST) {
+        const int32_t rowc = valid ? row : 0;
+        // round 2: the words the row id / position alone address (ids, selector, rating or g, biases: caches)
+        const int32_t rowh = head ? row : 0;
+        const int32_t pidw = FWD ? a.other[pos] : a.osel_in[pos];
+        if constexpr (FWD) cur = a.sel[rowc];
+        if constexpr (FWD) rvf = a.r[pos]; else gkf = a.g[pos];
+        ob = a.own_bias[rowc];
+        if constexpr (RMODE == RMODE_ADAM) {
+            mb = a.bias_m[rowh];
+            vb = a.bias_v[rowh];
+        }
+        // round 3: the rows, all four in one batch (the counter of outstanding loads retires in order: m and v go last, so
+        // the wait for the partner and own rows leaves them in flight behind the forward's arithmetic)
+        pidf = pidw & 0x7fffffff;
+        // `tok` is 0, but the compiler only learns that from an instruction that reads the partner id and the selector: every
+        // row address below carries it, so no row load can be scheduled ahead of the wait for those two words (it hoisted the
+        // m / v loads there, and the in-order wait for the partner id then waited for both rows)
+        int32_t tok;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(tok) : "v"(pidw), "v"(cur));
+        const int d0t = d0 + tok;
+        if constexpr (FWD) {
+            const ptrdiff_t alt = a.own_alt - a.own;
+            xf = load_full<VEC, true>(a.partner + (size_t)pidf * D + d0t);
+            o = load_full<VEC, true>(a.own + ((ptrdiff_t)(roff + d0t) + (cur ? alt : 0)));
+            pbf = a.partner_bias[pidf];
+        } else {
+            const ptrdiff_t alt = a.partner_alt - a.partner;
+            xf = load_full<VEC, true>(a.partner + ((ptrdiff_t)((size_t)pidf * D + d0t) + ((pidw < 0) ? alt : 0)));
+            o = load_full<VEC, true>(a.own + roff + d0t);
+        }
+        if constexpr (RMODE == RMODE_ADAM) {
+            const size_t mvoff = (head ? roff : 0) + d0t;
+            mrow = load_full<VEC, true>(a.m + mvoff);
+            vrow = load_full<VEC, true>(a.v + mvoff);
+        }
+    }
+    if (owner_side) {
         // owner side of the sharded step: the contribution is a gradient row already reduced by
         // a peer (it includes that peer's lam * Q[i] terms); just add them up in arrival order
         t = load_frag<VEC>(a.rows_in + (size_t)pos * (a.rstride ? a.rstride : D), d0, D);
@@ -938,10 +1008,17 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         }
     } else if (valid) {
         float gk = 0.f;
-        int32_t pid;
+        int32_t pid = 0;
         float lam_e;
         const float* ptab = a.partner;
         bool have = false;
+        float pb = 0.f, rv = 0.f;                        // FWD: partner bias, rating
+        Frag<VEC> x;
+      if constexpr (FAST) {
+        x = xf; pb = pbf; rv = rvf; gk = gkf; pid = pidf;
+        lam_e = a.lam;
+        if constexpr (FWD) { if (gl == 0) a.osel_out[pos] = row | (cur << 31); }
+      } else {
         if constexpr (!FWD) {
             if (a.ent) {                                             // FM: one 16-byte record per entry
                 const int4 e = a.ent[pos];
@@ -955,8 +1032,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             if (a.osel_in) { if (pid < 0) ptab = a.partner_alt; pid &= 0x7fffffff; }   // the table that still holds the pre-update row
             lam_e = a.lam;
         }
-        const Frag<VEC> x = a.partner_by_pos ? load_frag_h<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D, a.nt & 8)
-                                             : load_frag_h<VEC>(ptab + (size_t)pid * (a.pstride ? a.pstride : D), d0, D, a.nt & 1);
+        x = a.partner_by_pos ? load_frag_h<VEC>(a.partner_by_pos + (size_t)pos * D, d0, D, a.nt & 8)
+                             : load_frag_h<VEC>(ptab + (size_t)pid * (a.pstride ? a.pstride : D), d0, D, a.nt & 1);
         if (a.sel) {                                                 // two-table form: which table holds this row now
             cur = a.sel[row];
             if (gl == 0) a.osel_out[pos] = row | (cur << 31);
@@ -974,6 +1051,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         // this side updates its table in place before the other side runs: leave the other side the
         // pre-update row it needs, per entry
         if (a.own_copy_out) store_frag_h<VEC>(a.own_copy_out + (size_t)pos * D, d0, D, o, a.nt & 16);
+        if constexpr (FWD) { pb = a.partner_bias[pid]; rv = a.r[pos]; }
+      }
         if constexpr (FWD) {
             // K1 on the rows already in registers (item side: partner = P[u], own = Q[i]); same
             // arithmetic and order as forward_body
@@ -985,9 +1064,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
                 sq = fmaf(x.v[q], x.v[q], fmaf(qv, qv, sq));
             }
             sdot = group_sum<G>(sdot);
-            const float pb = a.partner_bias[pid];
             const float logit = ((sdot + *a.mu) + pb) + ob;
-            const float r = a.r[pos];
+            const float r = rv;
             float l;
             if (a.loss == 0) {
                 gk = logit - r;
@@ -1024,6 +1102,15 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     } else __syncthreads();
     if (!pstart) return;
 
+    // where the row is (two-table form: the table sel[row] named) and where its new value goes (the other table)
+    const ptrdiff_t walt = a.sel ? a.own_w_alt - a.own_w : 0;
+    const float* const wsrc = a.own_w + ((ptrdiff_t)roff + (cur ? walt : 0));
+    float* const wdst = a.own_w + ((ptrdiff_t)roff + (cur ? 0 : walt));
+    // FWD variant: the own row is re-read (an L2 hit) rather than kept live across the forward and the walk - four registers
+    // that decide whether two blocks fit a CU; FAST asks for it before the walk, not after it
+    Frag<VEC> wre;
+    if constexpr (FAST && FWD && LEAN && RMODE == RMODE_ADAM) wre = load_full<VEC, false>(wsrc + d0);
+
     Frag<VEC> acc = t;
     float gb = tb;
     int e = grp + 1;
@@ -1054,7 +1141,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         if (!go) break;
     }
     bool cont = false;                                   // does the run continue in the next block?
-    if (e == EPB && blk0 + EPB < Bn && !(a.tile && ((blk0 + EPB) % a.tile) == 0)) cont = (a.ks[blk0 + EPB] == row);
+    if (e == EPB && blk0 + EPB < Bn && !(a.tile && ((blk0 + EPB) % a.tile) == 0)) cont = (nextkey == row);
     const bool whole = head && !cont;
     if (RMODE == RMODE_SCRATCH && whole && a.dense_rows) {
         // dense-gradient form (TF1 Adam sweep / data parallel): a run that lies in one block goes
@@ -1069,16 +1156,17 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         }
     } else if constexpr (RMODE == RMODE_ADAM) {
         if (!a.frozen_rows) {
-            // FWD variant: the own row is re-read here (an L2 hit) rather than kept live across the walk -
-            // four registers that decide whether two blocks fit a CU
-            Frag<VEC> w = (FWD && LEAN) ? load_frag<VEC>((cur ? a.own_w_alt : a.own_w) + roff, d0, D) : o;
+            Frag<VEC> w;
+            if constexpr (FAST && FWD && LEAN) w = wre;
+            else w = (FWD && LEAN) ? load_frag<VEC>(wsrc, d0, D) : o;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], acc.v[q], c);
             // two-table form: the new row goes to the other table (the user side still reads the old one), then the row flips
-            store_frag_h<VEC>(((a.sel && !cur) ? a.own_w_alt : a.own_w) + roff, d0, D, w, a.nt & 4);
+            const bool nts = FAST || (a.nt & 4);
+            store_frag_h<VEC>(wdst, d0, D, w, nts);
             if (a.sel && gl == 0) a.sel[row] = cur ^ 1;
-            store_frag_h<VEC>(a.m + roff, d0, D, mrow, a.nt & 4);
-            store_frag_h<VEC>(a.v + roff, d0, D, vrow, a.nt & 4);
+            store_frag_h<VEC>(a.m + roff, d0, D, mrow, nts);
+            store_frag_h<VEC>(a.v + roff, d0, D, vrow, nts);
         }
         if (gl == 0 && !a.frozen_bias) {
             float w = ob;
@@ -1092,7 +1180,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             Frag<VEC> w = o;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) w.v[q] = w.v[q] - a.lr * acc.v[q];
-            store_frag<VEC>(((a.sel && !cur) ? a.own_w_alt : a.own_w) + roff, d0, D, w);
+            store_frag<VEC>(wdst, d0, D, w);
             if (a.sel && gl == 0) a.sel[row] = cur ^ 1;
         }
         if (gl == 0 && !a.frozen_bias) a.bias_w[row] = ob - a.lr * gb;
@@ -1718,9 +1806,22 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
     const dim3 grid((int)nb, n);
     static int lean = -1;                                // TFR_LEAN=0: A/B switch (own row kept in registers)
     if (lean < 0) { const char* e = getenv("TFR_LEAN"); lean = (e && e[0] == '0') ? 0 : 1; }
+    // FAST: the two-table big-table step in its plain layout (api.hip run_train_step, `dual`), default cache hints
+    static int fast_en = -1;                             // TFR_FAST=0: A/B switch
+    if (fast_en < 0) { const char* e = getenv("TFR_FAST"); fast_en = (e && e[0] == '0') ? 0 : 1; }
+    const RedArgs& a0 = p.a[0];
+    const bool plain = n == 1 && !a0.rows_in && !a0.ent && !a0.partner_by_pos && !a0.own_copy_out && !a0.ostride && !a0.obstride &&
+                       !a0.pstride && !a0.tile && a0.nt == 23 && a0.own == a0.own_w && a0.D == G * VEC && a0.B > 0;
+    const bool fast = fast_en && lean && plain && rmode != RMODE_SCRATCH &&
+                      (fwd ? (a0.sel && a0.osel_out && !a0.osel_in && a0.other && a0.own_alt && a0.own_alt == a0.own_w_alt && a0.r && a0.partner_bias)
+                           : (a0.osel_in && !a0.sel && a0.partner_alt && a0.g));
 #define TFR_RED_CASE(g, v)                                                                             \
     if (G == g && VEC == v) {                                                                          \
-        if (fwd && rmode == RMODE_ADAM && !lean) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, false>), grid, dim3(1024), 0, s, p); \
+        if (fast && fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, true, true>), grid, dim3(1024), 0, s, p); \
+        else if (fast && fwd) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD, true, true, true>), grid, dim3(1024), 0, s, p); \
+        else if (fast && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, false, true, true>), grid, dim3(1024), 0, s, p); \
+        else if (fast) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD, false, true, true>), grid, dim3(1024), 0, s, p); \
+        else if (fwd && rmode == RMODE_ADAM && !lean) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, false>), grid, dim3(1024), 0, s, p); \
         else if (fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true>), grid, dim3(1024), 0, s, p); \
         else if (fwd && rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH, true>), grid, dim3(1024), 0, s, p); \
         else if (fwd) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD, true>), grid, dim3(1024), 0, s, p); \
