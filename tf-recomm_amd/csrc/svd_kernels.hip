@@ -956,35 +956,34 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     int32_t pidf = 0;
     if constexpr (FAST) {
         const int32_t rowc = valid ? row : 0;
-        // round 2: the words the row id / position alone address (ids, selector, rating or g, biases: caches)
         const int32_t rowh = head ? row : 0;
-        const int32_t pidw = FWD ? a.other[pos] : a.osel_in[pos];
-        if constexpr (FWD) cur = a.sel[rowc];
+        // round 2: the words the row id / position alone address (ids, selector, rating or g, biases: caches)
+        const bool two_p = a.osel_in != nullptr;         // partner ids carry the table bit (two-table form, user side)
+        const int32_t* idp = two_p ? a.osel_in : a.other;
+        const int32_t pidw = idp[pos];
+        const int32_t* selp = a.sel ? a.sel : a.ks;      // no selector: a word that is there anyway, dropped
+        int32_t curw = selp[a.sel ? rowc : 0];
+        if (!a.sel) curw = 0;
         if constexpr (FWD) rvf = a.r[pos]; else gkf = a.g[pos];
-        ob = a.own_bias[rowc];
+        ob = a.own_bias[(size_t)rowc * (a.obstride ? a.obstride : 1)];
         if constexpr (RMODE == RMODE_ADAM) {
             mb = a.bias_m[rowh];
             vb = a.bias_v[rowh];
         }
-        // round 3: the rows, all four in one batch (the counter of outstanding loads retires in order: m and v go last, so
-        // the wait for the partner and own rows leaves them in flight behind the forward's arithmetic)
-        pidf = pidw & 0x7fffffff;
-        // `tok` is 0, but the compiler only learns that from an instruction that reads the partner id and the selector: every
-        // row address below carries it, so no row load can be scheduled ahead of the wait for those two words (it hoisted the
-        // m / v loads there, and the in-order wait for the partner id then waited for both rows)
+        // round 3: the rows, all four in one batch.  `tok` is 0, but the compiler only learns that from an instruction that reads
+        // the partner id and the selector: every row address carries it, so no row load can be scheduled ahead of the wait for
+        // those two words (it hoisted the m / v loads there, and the in-order wait for the partner id then waited for both rows)
+        pidf = two_p ? (pidw & 0x7fffffff) : pidw;
         int32_t tok;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(tok) : "v"(pidw), "v"(cur));
+        asm volatile("v_mov_b32 %0, 0" : "=v"(tok) : "v"(pidw), "v"(curw));
+        cur = curw;
         const int d0t = d0 + tok;
-        if constexpr (FWD) {
-            const ptrdiff_t alt = a.own_alt - a.own;
-            xf = load_full<VEC, true>(a.partner + (size_t)pidf * D + d0t);
-            o = load_full<VEC, true>(a.own + ((ptrdiff_t)(roff + d0t) + (cur ? alt : 0)));
-            pbf = a.partner_bias[pidf];
-        } else {
-            const ptrdiff_t alt = a.partner_alt - a.partner;
-            xf = load_full<VEC, true>(a.partner + ((ptrdiff_t)((size_t)pidf * D + d0t) + ((pidw < 0) ? alt : 0)));
-            o = load_full<VEC, true>(a.own + roff + d0t);
-        }
+        const ptrdiff_t oalt = a.own_alt ? a.own_alt - a.own : 0;
+        const ptrdiff_t palt = two_p ? a.partner_alt - a.partner : 0;
+        const int ostr = a.ostride ? a.ostride : D, pstr = a.pstride ? a.pstride : D;
+        xf = load_full<VEC, true>(a.partner + ((ptrdiff_t)((size_t)pidf * pstr + d0t) + ((pidw < 0) ? palt : 0)));
+        o = load_full<VEC, true>(a.own + ((ptrdiff_t)((size_t)rowc * ostr + d0t) + (cur ? oalt : 0)));
+        if constexpr (FWD) pbf = a.partner_bias[pidf];
         if constexpr (RMODE == RMODE_ADAM) {
             const size_t mvoff = (head ? roff : 0) + d0t;
             mrow = load_full<VEC, true>(a.m + mvoff);
@@ -1017,7 +1016,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
       if constexpr (FAST) {
         x = xf; pb = pbf; rv = rvf; gk = gkf; pid = pidf;
         lam_e = a.lam;
-        if constexpr (FWD) { if (gl == 0) a.osel_out[pos] = row | (cur << 31); }
+        if constexpr (FWD) { if (gl == 0 && a.osel_out) a.osel_out[pos] = row | (cur << 31); }
       } else {
         if constexpr (!FWD) {
             if (a.ent) {                                             // FM: one 16-byte record per entry
@@ -1806,19 +1805,23 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
     const dim3 grid((int)nb, n);
     static int lean = -1;                                // TFR_LEAN=0: A/B switch (own row kept in registers)
     if (lean < 0) { const char* e = getenv("TFR_LEAN"); lean = (e && e[0] == '0') ? 0 : 1; }
-    // FAST: the two-table big-table step in its plain layout (api.hip run_train_step, `dual`), default cache hints
+    // FAST: full-width rows (D = G * VEC), ids and rows from tables or packed exchange buffers (strides), with or without the
+    // two-table item form - the fused big-table step (api.hip run_train_step, `dual`) and the row-sharded step's item / user
+    // sides; not the per-position copies of the one-table form, the FM records, the owners' pre-reduced rows or tile mode.
+    // Its row loads are non-temporal whatever RedArgs::nt says.
     static int fast_en = -1;                             // TFR_FAST=0: A/B switch
     if (fast_en < 0) { const char* e = getenv("TFR_FAST"); fast_en = (e && e[0] == '0') ? 0 : 1; }
     const RedArgs& a0 = p.a[0];
-    const bool plain = n == 1 && !a0.rows_in && !a0.ent && !a0.partner_by_pos && !a0.own_copy_out && !a0.ostride && !a0.obstride &&
-                       !a0.pstride && !a0.tile && a0.nt == 23 && a0.own == a0.own_w && a0.D == G * VEC && a0.B > 0;
-    const bool fast = fast_en && lean && plain && rmode != RMODE_SCRATCH &&
-                      (fwd ? (a0.sel && a0.osel_out && !a0.osel_in && a0.other && a0.own_alt && a0.own_alt == a0.own_w_alt && a0.r && a0.partner_bias)
-                           : (a0.osel_in && !a0.sel && a0.partner_alt && a0.g));
+    const bool fast = fast_en && lean && n == 1 && !a0.rows_in && !a0.ent && !a0.partner_by_pos && !a0.own_copy_out && !a0.tile &&
+                      a0.D == G * VEC && a0.B > 0 && a0.other && (!a0.osel_in || a0.partner_alt) && (!a0.sel || (a0.own_alt && a0.own_alt == a0.own_w_alt)) &&
+                      (rmode == RMODE_SCRATCH || (a0.own == a0.own_w && !a0.ostride)) &&
+                      (fwd ? (a0.r && a0.partner_bias && !a0.osel_in) : (a0.g && !a0.sel));
 #define TFR_RED_CASE(g, v)                                                                             \
     if (G == g && VEC == v) {                                                                          \
         if (fast && fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, true, true>), grid, dim3(1024), 0, s, p); \
+        else if (fast && fwd && rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH, true, true, true>), grid, dim3(1024), 0, s, p); \
         else if (fast && fwd) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD, true, true, true>), grid, dim3(1024), 0, s, p); \
+        else if (fast && rmode == RMODE_SCRATCH) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SCRATCH, false, true, true>), grid, dim3(1024), 0, s, p); \
         else if (fast && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, false, true, true>), grid, dim3(1024), 0, s, p); \
         else if (fast) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_SGD, false, true, true>), grid, dim3(1024), 0, s, p); \
         else if (fwd && rmode == RMODE_ADAM && !lean) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, false>), grid, dim3(1024), 0, s, p); \
