@@ -952,7 +952,9 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     // three rounds.  `cond ? a.p : a.q` on two kernel-argument pointers would be compiled into a VECTOR load of the pointer from
     // the argument block at a selected offset - a dependent round trip of its own; the table is chosen by an offset instead.
     Frag<VEC> xf;
-    float pbf = 0.f, rvf = 0.f, gkf = 0.f;
+    // (lam through a scalar-register read: `ent ? record.z : a.lam` would otherwise become ONE vector load from a selected
+    // address - the argument block or the record - with a round trip of its own)
+    float pbf = 0.f, rvf = 0.f, gkf = 0.f, lamf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.lam)));
     int32_t pidf = 0;
     if constexpr (FAST) {
         const int32_t rowc = valid ? row : 0;
@@ -960,11 +962,20 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         // round 2: the words the row id / position alone address (ids, selector, rating or g, biases: caches)
         const bool two_p = a.osel_in != nullptr;         // partner ids carry the table bit (two-table form, user side)
         const int32_t* idp = two_p ? a.osel_in : a.other;
-        const int32_t pidw = idp[pos];
+        int32_t pidw;
+        if constexpr (FWD) {
+            pidw = idp[pos];
+            rvf = a.r[pos];
+        } else if (a.ent) {                              // FM: partner row, g x and the entry's coefficient in one 16-byte record
+            const int4 e = a.ent[pos];
+            pidw = e.x; gkf = __int_as_float(e.y); lamf = __int_as_float(e.z);
+        } else {
+            pidw = idp[pos];
+            gkf = a.g[pos];
+        }
         const int32_t* selp = a.sel ? a.sel : a.ks;      // no selector: a word that is there anyway, dropped
         int32_t curw = selp[a.sel ? rowc : 0];
         if (!a.sel) curw = 0;
-        if constexpr (FWD) rvf = a.r[pos]; else gkf = a.g[pos];
         ob = a.own_bias[(size_t)rowc * (a.obstride ? a.obstride : 1)];
         if constexpr (RMODE == RMODE_ADAM) {
             mb = a.bias_m[rowh];
@@ -1015,7 +1026,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         Frag<VEC> x;
       if constexpr (FAST) {
         x = xf; pb = pbf; rv = rvf; gk = gkf; pid = pidf;
-        lam_e = a.lam;
+        lam_e = lamf;
         if constexpr (FWD) { if (gl == 0 && a.osel_out) a.osel_out[pos] = row | (cur << 31); }
       } else {
         if constexpr (!FWD) {
@@ -1807,15 +1818,16 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
     if (lean < 0) { const char* e = getenv("TFR_LEAN"); lean = (e && e[0] == '0') ? 0 : 1; }
     // FAST: full-width rows (D = G * VEC), ids and rows from tables or packed exchange buffers (strides), with or without the
     // two-table item form - the fused big-table step (api.hip run_train_step, `dual`) and the row-sharded step's item / user
-    // sides; not the per-position copies of the one-table form, the FM records, the owners' pre-reduced rows or tile mode.
+    // sides, the FM backward (16-byte entry records); not the per-position copies of the one-table form, the owners'
+    // pre-reduced rows or tile mode.
     // Its row loads are non-temporal whatever RedArgs::nt says.
     static int fast_en = -1;                             // TFR_FAST=0: A/B switch
     if (fast_en < 0) { const char* e = getenv("TFR_FAST"); fast_en = (e && e[0] == '0') ? 0 : 1; }
     const RedArgs& a0 = p.a[0];
-    const bool fast = fast_en && lean && n == 1 && !a0.rows_in && !a0.ent && !a0.partner_by_pos && !a0.own_copy_out && !a0.tile &&
-                      a0.D == G * VEC && a0.B > 0 && a0.other && (!a0.osel_in || a0.partner_alt) && (!a0.sel || (a0.own_alt && a0.own_alt == a0.own_w_alt)) &&
+    const bool fast = fast_en && lean && n == 1 && !a0.rows_in && !a0.partner_by_pos && !a0.own_copy_out && !a0.tile &&
+                      a0.D == G * VEC && a0.B > 0 && (a0.other || a0.ent) && (!a0.ent || (!fwd && !a0.osel_in)) && (!a0.osel_in || a0.partner_alt) && (!a0.sel || (a0.own_alt && a0.own_alt == a0.own_w_alt)) &&
                       (rmode == RMODE_SCRATCH || (a0.own == a0.own_w && !a0.ostride)) &&
-                      (fwd ? (a0.r && a0.partner_bias && !a0.osel_in) : (a0.g && !a0.sel));
+                      (fwd ? (a0.r && a0.partner_bias && !a0.osel_in) : ((a0.g || a0.ent) && !a0.sel));
 #define TFR_RED_CASE(g, v)                                                                             \
     if (G == g && VEC == v) {                                                                          \
         if (fast && fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, true, true>), grid, dim3(1024), 0, s, p); \
