@@ -956,7 +956,30 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     // address - the argument block or the record - with a round trip of its own)
     float pbf = 0.f, rvf = 0.f, gkf = 0.f, lamf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.lam)));
     int32_t pidf = 0;
-    if constexpr (FAST) {
+    bool fast_owner = false;
+    if constexpr (FAST && !FWD) fast_owner = a.rows_in != nullptr;
+    if (fast_owner) {
+        // owner side of the row-sharded step: the contributions are gradient rows already reduced by the peers (by arrival
+        // position); everything is addressed by the row id / position alone - one round
+        const int32_t rowh = head ? row : 0;
+        const int rstr = a.rstride ? a.rstride : D;
+        t = load_full<VEC, true>(a.rows_in + (size_t)pos * rstr + d0);
+        tb = a.bias_in[(size_t)pos * (a.rbstride ? a.rbstride : 1)];
+        o = load_full<VEC, true>(a.own + roff + d0);
+        ob = a.own_bias[valid ? row : 0];
+        if constexpr (RMODE == RMODE_ADAM) {
+            const size_t mvoff = (head ? roff : 0) + d0;
+            mrow = load_full<VEC, true>(a.m + mvoff);
+            vrow = load_full<VEC, true>(a.v + mvoff);
+            mb = a.bias_m[rowh];
+            vb = a.bias_v[rowh];
+        }
+        if (!valid) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) t.v[q] = 0.f;
+            tb = 0.f;
+        }
+    } else if constexpr (FAST) {
         const int32_t rowc = valid ? row : 0;
         const int32_t rowh = head ? row : 0;
         // round 2: the words the row id / position alone address (ids, selector, rating or g, biases: caches)
@@ -1001,7 +1024,9 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             vrow = load_full<VEC, true>(a.v + mvoff);
         }
     }
-    if (owner_side) {
+    if (fast_owner) {
+        // loaded above
+    } else if (owner_side) {
         // owner side of the sharded step: the contribution is a gradient row already reduced by
         // a peer (it includes that peer's lam * Q[i] terms); just add them up in arrival order
         t = load_frag<VEC>(a.rows_in + (size_t)pos * (a.rstride ? a.rstride : D), d0, D);
@@ -1818,16 +1843,19 @@ void launch_seg_reduce(const RedPair& p, int n, int rmode, int G, int VEC, hipSt
     if (lean < 0) { const char* e = getenv("TFR_LEAN"); lean = (e && e[0] == '0') ? 0 : 1; }
     // FAST: full-width rows (D = G * VEC), ids and rows from tables or packed exchange buffers (strides), with or without the
     // two-table item form - the fused big-table step (api.hip run_train_step, `dual`) and the row-sharded step's item / user
-    // sides, the FM backward (16-byte entry records); not the per-position copies of the one-table form, the owners'
-    // pre-reduced rows or tile mode.
+    // sides and its owners' apply (pre-reduced rows), the FM backward (16-byte entry records); not the per-position copies of
+    // the one-table form or tile mode.
     // Its row loads are non-temporal whatever RedArgs::nt says.
     static int fast_en = -1;                             // TFR_FAST=0: A/B switch
     if (fast_en < 0) { const char* e = getenv("TFR_FAST"); fast_en = (e && e[0] == '0') ? 0 : 1; }
     const RedArgs& a0 = p.a[0];
-    const bool fast = fast_en && lean && n == 1 && !a0.rows_in && !a0.partner_by_pos && !a0.own_copy_out && !a0.tile &&
+    const bool fast_own = fast_en && lean && n == 1 && a0.rows_in && a0.bias_in && !fwd && !a0.tile && !a0.sel && !a0.ostride && !a0.obstride &&
+                          a0.D == G * VEC && a0.B > 0 && (rmode == RMODE_SCRATCH || a0.own == a0.own_w);
+    const bool fast = fast_own ||
+                      (fast_en && lean && n == 1 && !a0.rows_in && !a0.partner_by_pos && !a0.own_copy_out && !a0.tile &&
                       a0.D == G * VEC && a0.B > 0 && (a0.other || a0.ent) && (!a0.ent || (!fwd && !a0.osel_in)) && (!a0.osel_in || a0.partner_alt) && (!a0.sel || (a0.own_alt && a0.own_alt == a0.own_w_alt)) &&
                       (rmode == RMODE_SCRATCH || (a0.own == a0.own_w && !a0.ostride)) &&
-                      (fwd ? (a0.r && a0.partner_bias && !a0.osel_in) : ((a0.g || a0.ent) && !a0.sel));
+                      (fwd ? (a0.r && a0.partner_bias && !a0.osel_in) : ((a0.g || a0.ent) && !a0.sel)));
 #define TFR_RED_CASE(g, v)                                                                             \
     if (G == g && VEC == v) {                                                                          \
         if (fast && fwd && rmode == RMODE_ADAM) hipLaunchKernelGGL((k_seg_reduce<g, v, RMODE_ADAM, true, true, true>), grid, dim3(1024), 0, s, p); \
