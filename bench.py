@@ -253,7 +253,7 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
     per_launch = B * (8 * D + 20)
     gbs = per_launch / (ms / n * 1e-3) / 1e9
     chk = float(out.double().sum().item())
-    # same-device yardstick: the library's own float4 grid-stride copy kernel over 1 GiB (read + write bytes); the guide's
+    # same-device yardstick: the library's own float4 copy kernel (one element per thread, streaming loads and stores) over 1 GiB (read + write bytes); the guide's
     # figure for this kernel shape is 6.29 TB/s (STREAM_CEILING_GBS)
     copy_gbs, copy_mean = T.device_copy_rate(device, 1 << 30, 10)
     G = lane_group(D)
@@ -274,7 +274,7 @@ def north_star_forward(device, steps=100, warmup=10, U=10_000_000, I=1_000_000, 
                 ratings_per_s=B * n / (ms * 1e-3), wall_ratings_per_s=B * steps / wall,
                 stream_ceiling_GBps=STREAM_CEILING_GBS, frac_of_stream_ceiling=gbs / STREAM_CEILING_GBS,
                 device_copy_GBps=copy_gbs, device_copy_mean_GBps=copy_mean, frac_of_device_copy=gbs / copy_gbs,
-                device_copy_note="tfr_device_copy_rate: float4 grid-stride copy kernel of this library, 1 GiB, best of 10 launches")
+                device_copy_note="tfr_device_copy_rate: float4 copy kernel of this library (one 16-byte element per thread, streaming loads and stores: the fastest form on this part, tools/probes/copy_bw.hip), 1 GiB, best of 10 launches")
 
 
 def fm_forward_bench(device, steps=50, warmup=5, F=1_000_000, D=64, n=1 << 20, nnz=8, no_cpu=False):

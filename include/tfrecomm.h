@@ -370,8 +370,9 @@ int tfr_sync(tfr_model* m);            /* drains the stream; reports deferred TF
 const char* tfr_last_error(void);
 int tfr_version(void);
 int tfr_device_count(void);
-/* Measurement yardstick (bench.py): GB/s (read + write bytes) of the library's own float4 grid-stride copy kernel over
- * `bytes` of device memory, best and mean of `reps` launches timed by HIP events.  Replaces no reference call. */
+/* Measurement yardstick (bench.py): GB/s (read + write bytes) of the library's own float4 copy kernel (one 16-byte element per
+ * thread, streaming loads and stores - the fastest of the forms tools/probes/copy_bw.hip compares) over `bytes` of device
+ * memory, best and mean of `reps` launches timed by HIP events.  Replaces no reference call. */
 int tfr_device_copy_rate(int32_t device, int64_t bytes, int32_t reps, double* best_gbs, double* mean_gbs);
 
 #ifdef __cplusplus

@@ -374,16 +374,19 @@ int tfr_device_count(void) {
 
 // ---- measurement yardstick: what a plain float4 read+write copy reaches on this device ---------------------------
 // (MI355X_MICROARCH.md quotes 6.29 TB/s for exactly this shape of kernel; bench.py prints both)
-__global__ void __launch_bounds__(256) k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
+// the copy form that is fastest on this part (tools/probes/copy_bw.hip: one 16-byte element per thread, short-lived workgroups in
+// address order, streaming loads and stores - 6.2-6.5 TB/s where a grid-stride loop over the same bytes gives 4.8)
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_copy_f4(const copy_f4* __restrict__ src, copy_f4* __restrict__ dst, int64_t n4) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[k]), &dst[k]);
 }
 
 int tfr_device_copy_rate(int32_t device, int64_t bytes, int32_t reps, double* best_gbs, double* mean_gbs) {
     if (bytes < (1 << 20) || reps < 1 || reps > 1000 || !best_gbs) return fail(TFR_ERR_ARG, "tfr_device_copy_rate: bad argument");
     HIPCHK(hipSetDevice(device));
     const int64_t n4 = bytes / 16;
-    float4 *a = nullptr, *b = nullptr;
+    copy_f4 *a = nullptr, *b = nullptr;
     HIPCHK(hipMalloc(&a, n4 * 16));
     if (hipMalloc(&b, n4 * 16) != hipSuccess) { (void)hipFree(a); return fail(TFR_ERR_NOMEM, "tfr_device_copy_rate: out of memory"); }
     hipStream_t st;
@@ -392,7 +395,7 @@ int tfr_device_copy_rate(int32_t device, int64_t bytes, int32_t reps, double* be
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    const int grid = 256 * 8;                               // 256 CUs x 8 blocks of 256 threads, grid-stride
+    const unsigned grid = (unsigned)((n4 + 255) / 256);
     double best = 0.0, sum = 0.0;
     for (int r = -2; r < reps; ++r) {
         (void)hipEventRecord(e0, st);

@@ -241,31 +241,54 @@ void launch_route_slots(const RouteArgs& a, hipStream_t s) {
 template <int G, int VEC>
 __global__ __launch_bounds__(256) void k_gather_packed(GatherPackedArgs a) {
     constexpr int GPB = 256 / G;
+    constexpr int UN = 4;                                // requests in flight per lane group: ids in one round, rows in the next
     const int gl = threadIdx.x % G, d0 = gl * VEC;
     bool oob = false;
     const float flag = (float)(*a.err != 0);
-    for (int64_t j = (int64_t)blockIdx.x * GPB + threadIdx.x / G; j < a.n; j += (int64_t)gridDim.x * GPB) {
-        const int32_t id = a.ids[j];
-        float* dst = a.out + (size_t)j * a.stride;
-        float v[VEC];
+    const bool full = a.D == G * VEC;                    // full-width rows: unguarded 16-byte loads (block-uniform)
+    for (int64_t j0 = (int64_t)blockIdx.x * GPB * UN + threadIdx.x / G; j0 < a.n; j0 += (int64_t)gridDim.x * GPB * UN) {
+        int32_t id[UN];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) v[q] = 0.f;
-        float b = 0.f;
-        if (id >= 0) {
-            if ((int64_t)id >= a.rows) oob = true;
-            else {
+        for (int u = 0; u < UN; ++u) {
+            const int64_t j = j0 + (int64_t)u * GPB;
+            id[u] = a.ids[j < a.n ? j : j0];
+        }
+        float v[UN][VEC], b[UN];
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) if (d0 + q < a.D) v[q] = a.table[(size_t)id * a.D + d0 + q];
-                b = a.bias[id];
+        for (int u = 0; u < UN; ++u) {
+            const bool bad = id[u] >= 0 && (int64_t)id[u] >= a.rows;
+            oob |= bad && (j0 + (int64_t)u * GPB < a.n);
+            const int32_t idc = (id[u] >= 0 && !bad) ? id[u] : 0;     // an address that is there; the value is dropped below
+            const float* src = a.table + (size_t)idc * a.D;
+            if constexpr (VEC == 4) {
+                if (full) {
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src + d0));
+                    v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[u][q] = (d0 + q < a.D) ? src[d0 + q] : 0.f;
+                }
+            } else {
+                v[u][0] = (d0 < a.D) ? src[d0] : 0.f;
             }
+            b[u] = a.bias[idc];
         }
-        if (d0 < a.D) {
-            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + d0) = make_float4(v[0], v[1], v[2], v[3]);
-            else dst[d0] = v[0];
-        }
-        if (gl == 0) {
-            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + a.D) = make_float4(b, flag, 0.f, 0.f);
-            else { dst[a.D] = b; dst[a.D + 1] = flag; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t j = j0 + (int64_t)u * GPB;
+            if (j >= a.n) break;
+            const bool keep = id[u] >= 0 && (int64_t)id[u] < a.rows;
+            float* dst = a.out + (size_t)j * a.stride;
+            if (d0 < a.D) {
+                if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + d0) = keep ? make_float4(v[u][0], v[u][1], v[u][2], v[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                else dst[d0] = keep ? v[u][0] : 0.f;
+            }
+            if (gl == 0) {
+                const float bb = keep ? b[u] : 0.f;
+                if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + a.D) = make_float4(bb, flag, 0.f, 0.f);
+                else { dst[a.D] = bb; dst[a.D + 1] = flag; }
+            }
         }
     }
     if (oob) atomicOr(a.err, 1);
@@ -283,7 +306,7 @@ void launch_adopt_peer_err(const float* rows, int64_t chunk_floats, int32_t worl
 }
 
 void launch_gather_packed(const GatherPackedArgs& a, int G, int VEC, hipStream_t s) {
-    const int gpb = 256 / G;
+    const int gpb = 4 * (256 / G);                       // UN requests per lane group and round
     int64_t nb = (a.n + gpb - 1) / gpb;
     if (nb > 8192) nb = 8192;
     if (nb < 1) nb = 1;

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
                 float xv = side == 0 ? q[h].v[e] : p[h].v[e];
                 if (side == 0) { if (a.item_abs) xv = fabsf(xv); }
                 else if (a.item_abs) xv = xv * ((ov > 0.f) ? 1.f : ((ov < 0.f) ? -1.f : 0.f));
-                acc[h].v[e] = gk * xv + a.lam * ov;
+                acc[h].v[e] = fmaf(gk, xv, a.lam * ov);
             }
             gb[h] = a.reg_bias ? (gk + a.lam * ob) : gk;
         }
@@ -867,8 +867,8 @@ struct AdamC { float alpha, b1, b2, eps, omb1, omb2; };
 // AdamOptimizer._apply_sparse_shared [TF1-lib]: m*b1 + g*(1-b1); v*b2 + g*g*(1-b2);
 // var - alpha*m/(sqrt(v)+eps)
 __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float g, const AdamC& c) {
-    m = m * c.b1 + g * c.omb1;
-    v = v * c.b2 + (g * g) * c.omb2;
+    m = fmaf(m, c.b1, g * c.omb1);                       // which product is fused is pinned here: left to the compiler it
+    v = fmaf(v, c.b2, (g * g) * c.omb2);                 // differed between instantiations of the same kernel
     w = w - c.alpha * m / (sqrtf(v) + c.eps);
 }
 
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             float xv = x.v[q];
             if (a.side == 0) { if (a.item_abs) xv = fabsf(xv); }
             else if (a.item_abs) xv = xv * ((o.v[q] > 0.f) ? 1.f : ((o.v[q] < 0.f) ? -1.f : 0.f));
-            t.v[q] = gk * xv + lam_e * o.v[q];
+            t.v[q] = fmaf(gk, xv, lam_e * o.v[q]);        // pinned: left to the compiler, the fused product differed between instantiations
         }
         tb = a.reg_bias ? (gk + a.lam * ob) : gk;
     }
