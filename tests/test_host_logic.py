@@ -130,8 +130,8 @@ def test_bench_finds_the_committed_counter_summaries():
     import bench
     r = bench.PROFILE_ROUND
     for fname, kern in ((r + "_pmc_c2.csv", "k_tile_step<16, 4, 2>"), (r + "_pmc_c2.csv", "k_dense_tiles<16, 4, false, 10>"),
-                        (r + "_pmc_c3.csv", "k_seg_reduce<32, 4, 1, true, true>"), (r + "_pmc_c3.csv", "k_seg_reduce<32, 4, 1, false, true>"),
-                        (r + "_pmc_c4.csv", "k_seg_reduce<32, 4, 1, true, true>"), (r + "_pmc_c5.csv", "k_fm_forward<16, 4, false, true>"),
+                        (r + "_pmc_c3.csv", "k_seg_reduce<32, 4, 1, true, true, true>"), (r + "_pmc_c3.csv", "k_seg_reduce<32, 4, 1, false, true, true>"),
+                        (r + "_pmc_c4.csv", "k_seg_reduce<32, 4, 1, true, true, true>"), (r + "_pmc_c5.csv", "k_fm_forward<16, 4, false, true>"),
                         (r + "_pmc_forward_uniform.csv", "k_forward<32, 4, 0, 4, true>"), (r + "_pmc_forward_zipf.csv", "k_forward<32, 4, 0, 4, true>"),
                         (r + "_pmc_forward_8x_batch.csv", "k_forward<32, 4, 0, 4, true>")):
         t = bench.profiled_traffic(fname, kern)

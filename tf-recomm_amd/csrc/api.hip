@@ -2158,15 +2158,18 @@ int tfr_kernel_plan(tfr_model* m, int64_t B, char* buf, int64_t buflen) {
                  tile_step_epg((int)ntiles, G, V), G, V, nt);
     } else if (!tf1 && !csort) {
         const int rm = adam ? RMODE_ADAM : RMODE_SGD;
-        snprintf(tmp, sizeof(tmp), "sort=%s x%d passes (the first gathers the batch);reduce_item=k_seg_reduce<%d, %d, %d, true, true>;"
-                 "reduce_user=k_seg_reduce<%d, %d, %d, false, true>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
+        // the sixth argument: the three-round load form (launch_seg_reduce picks it for the two-table step on full-width rows)
+        const char* e1 = getenv("TFR_DUALQ"); const char* e2 = getenv("TFR_FAST"); const char* e3 = getenv("TFR_LEAN");
+        const bool fast = !(e1 && e1[0] == '0') && !(e2 && e2[0] == '0') && !(e3 && e3[0] == '0') && m->D == G * V;
+        snprintf(tmp, sizeof(tmp), "sort=%s x%d passes (the first gathers the batch);reduce_item=k_seg_reduce<%d, %d, %d, true, true, %s>;"
+                 "reduce_user=k_seg_reduce<%d, %d, %d, false, true, %s>;apply=k_apply_rows<%d, %d, %d>",   // K4 rides in the apply launch
                  rsortw_eligible(B) ? "k_rsortw_hist/k_rsort_scan/k_rsortw_scatter" : "k_rsort_rank/scan/scatter",
-                 ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, G, V, rm, G, V, adam ? 0 : 1);
+                 ((m->bits_u > m->bits_i ? m->bits_u : m->bits_i) + 7) / 8, G, V, rm, fast ? "true" : "false", G, V, rm, fast ? "true" : "false", G, V, adam ? 0 : 1);
     } else if (csort) {
-        snprintf(tmp, sizeof(tmp), "forward=k_front<%d, %d>;sort=k_csort_scan/scatter;reduce_item=k_seg_reduce<%d, %d, %d, false, true>;apply=%s",
+        snprintf(tmp, sizeof(tmp), "forward=k_front<%d, %d>;sort=k_csort_scan/scatter;reduce_item=k_seg_reduce<%d, %d, %d, false, true, false>;apply=%s",
                  G, V, G, V, tf1 ? RMODE_SCRATCH : (adam ? RMODE_ADAM : RMODE_SGD), tf1 ? "k_adam_dense" : "k_apply_rows");
     } else {
-        snprintf(tmp, sizeof(tmp), "forward=k_forward<%d, %d, 1, 4, false>;sort=k_rsort_rank/scan/scatter;reduce_item=k_seg_reduce<%d, %d, 0, false, true>;apply=k_adam_dense<%d, %d>;finalize=k_finalize",
+        snprintf(tmp, sizeof(tmp), "forward=k_forward<%d, %d, 1, 4, false>;sort=k_rsort_rank/scan/scatter;reduce_item=k_seg_reduce<%d, %d, 0, false, true, false>;apply=k_adam_dense<%d, %d>;finalize=k_finalize",
                  G, V, G, V, G, V);
     }
     snprintf(buf, (size_t)buflen, "%s", tmp);

@@ -19,7 +19,7 @@ def short(nm):
     return nm[:nm.index("(")] if "(" in nm else nm
 
 
-items = [e for e in ev if "k_seg_reduce" in e[2] and "true, true" in e[2]]
+items = [e for e in ev if "k_seg_reduce" in e[2] and ", true, true, " in e[2]]
 print("item-side launches:", len(items))
 per = [(items[k + 1][0] - items[k][0]) / 1e3 for k in range(len(items) - 1)]
 print("step period us (item start to item start): median %.1f min %.1f max %.1f" % (sorted(per)[len(per) // 2], min(per), max(per)))
