@@ -899,6 +899,10 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 //     partner and own rows - so a block spends one HBM latency on its rows, not three in a row.
 template <int G, int VEC, int RMODE, bool FWD = false, bool LEAN = true, bool FAST = false>
 __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
+    // FAST, where the m / v rows of non-head entries are not needed: the item side skips their loads under a branch (a fifth
+    // of its entries repeat a row: 190 -> 184 us, Zipf 146 -> 136), the user side - hardly any repeats - reads row 0 instead
+    // and stays branch-free (175.5 against 177.3 us); A/B of two builds in one call, tools/ab_mv.sh
+    constexpr bool MV_BRANCH = FWD;
     constexpr int EPB = 1024 / G;
     __shared__ float lds_t[EPB * G * VEC];
     __shared__ float lds_gb[EPB];
@@ -945,7 +949,11 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     int32_t cur = 0;                                     // two-table form: the table this entry's own row is in
     float facc[3] = {0.f, 0.f, 0.f};                     // FWD: this lane's {loss, reg, g} share
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) { o.v[q] = 0.f; t.v[q] = 0.f; mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
+    for (int q = 0; q < VEC; ++q) { o.v[q] = 0.f; t.v[q] = 0.f; }
+    if constexpr (!(FAST && MV_BRANCH)) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) { mrow.v[q] = 0.f; vrow.v[q] = 0.f; }
+    }
     bool owner_side = false;
     if constexpr (!FAST) owner_side = valid && a.rows_in;
     // FAST: the loads, branch-free (lanes past the entries and non-head lanes read row / position 0 and drop the result) and in
@@ -1019,9 +1027,16 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         o = load_full<VEC, true>(a.own + ((ptrdiff_t)((size_t)rowc * ostr + d0t) + (cur ? oalt : 0)));
         if constexpr (FWD) pbf = a.partner_bias[pidf];
         if constexpr (RMODE == RMODE_ADAM) {
-            const size_t mvoff = (head ? roff : 0) + d0t;
-            mrow = load_full<VEC, true>(a.m + mvoff);
-            vrow = load_full<VEC, true>(a.v + mvoff);
+            if (MV_BRANCH) {
+                if (head) {
+                    mrow = load_full<VEC, true>(a.m + roff + d0t);
+                    vrow = load_full<VEC, true>(a.v + roff + d0t);
+                }
+            } else {
+                const size_t mvoff = (head ? roff : 0) + d0t;
+                mrow = load_full<VEC, true>(a.m + mvoff);
+                vrow = load_full<VEC, true>(a.v + mvoff);
+            }
         }
     }
     if (fast_owner) {
