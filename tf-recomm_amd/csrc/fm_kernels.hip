@@ -28,6 +28,10 @@ __global__ __launch_bounds__(256) void k_fm_forward(FmArgs a) {
     const int D = a.D;
     const float mu = *a.mu;
     bool oob = false;
+    // full-width rows (block-uniform): unguarded 16-byte loads.  Behind a `d0 < D` guard each row load is merged with a
+    // zero-initialised copy afterwards - a register move behind a FULL wait, so the four rows "in flight" arrived one after the
+    // other (ISA: global_load_dwordx4 / s_waitcnt vmcnt(0) four times in a row)
+    const bool full = D == G * VEC;
     float acc3[3] = {0.f, 0.f, 0.f};           // TRAIN: data loss, -, sum g
     for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / G; row < a.n_rows;
          row += (int64_t)gridDim.x * GPB) {
@@ -40,14 +44,34 @@ __global__ __launch_bounds__(256) void k_fm_forward(FmArgs a) {
             int32_t f[4];
             float x[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {                // branch-free: an address that is there, the value dropped
                 const bool ok = p + j < hi;
-                f[j] = ok ? a.indices[p + j] : 0;
-                x[j] = ok ? a.data[p + j] : 0.f;
+                const int64_t pj = ok ? p + j : hi - 1;
+                const int32_t fj = a.indices[pj];
+                const float xj = a.data[pj];
+                f[j] = ok ? fj : 0;
+                x[j] = ok ? xj : 0.f;
                 if ((uint64_t)(int64_t)f[j] >= (uint64_t)a.F) { oob = true; f[j] = 0; x[j] = 0.f; }
             }
             float v[4][VEC];
             float w[4];
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = a.W[f[j]];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* vr = a.V + (size_t)f[j] * D + d0;
+                    if constexpr (VEC == 4) {
+                        typedef float f4v __attribute__((ext_vector_type(4)));
+                        f4v t;
+                        if constexpr (NTV) t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(vr));
+                        else t = *reinterpret_cast<const f4v*>(vr);
+                        v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+                    } else {
+                        v[j][0] = NTV ? __builtin_nontemporal_load(vr) : *vr;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float* vr = a.V + (size_t)f[j] * D;
@@ -67,6 +91,7 @@ __global__ __launch_bounds__(256) void k_fm_forward(FmArgs a) {
                     v[j][0] = (d0 < D) ? (NTV ? __builtin_nontemporal_load(vr + d0) : vr[d0]) : 0.f;
                 }
                 w[j] = a.W[f[j]];
+            }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
