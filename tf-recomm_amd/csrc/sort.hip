@@ -314,22 +314,45 @@ __global__ __launch_bounds__(1024) void k_rsortw_hist(RSortArgs a) {
     __syncthreads();
     const int64_t k0 = (int64_t)tile * RW_TILE + (tid >> 6) * 256 + (tid & 63);
     bool bad = false;
+    // the thread's four keys in ONE round of loads (two with the fused gather: ids, then records), not one round per key: the
+    // wave's loads were issued and waited for key by key, and a 64-tile launch is nothing but latency.  Keys past the end read
+    // the last key's address and are dropped.
+    int32_t key[RW_KPT];
+    bool ok[RW_KPT];
+    const int64_t last = a.B - 1;
+    if (a.ids) {                                         // fused gather (first pass only): this pass reads the store records itself
+        int64_t id[RW_KPT];
+#pragma unroll
+        for (int r = 0; r < RW_KPT; ++r) {
+            const int64_t k = k0 + r * 64;
+            ok[r] = k < a.B;
+            id[r] = a.ids[ok[r] ? k : last];
+        }
+        int4 rec[RW_KPT];
+#pragma unroll
+        for (int r = 0; r < RW_KPT; ++r) {
+            if ((uint64_t)id[r] >= (uint64_t)a.N) { if (a.err && ok[r]) atomicOr(a.err, 2); id[r] = 0; }
+            rec[r] = a.store[id[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < RW_KPT; ++r) {
+            const int64_t k = k0 + r * 64;
+            key[r] = col == 0 ? rec[r].x : rec[r].y;
+            if (col == 0 && ok[r]) { a.u_out[k] = rec[r].x; a.i_out[k] = rec[r].y; a.r_out[k] = __int_as_float(rec[r].z); }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RW_KPT; ++r) {
+            const int64_t k = k0 + r * 64;
+            ok[r] = k < a.B;
+            key[r] = a.keys_in[col][ok[r] ? k : last];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RW_KPT; ++r) {
-        const int64_t k = k0 + r * 64;
-        if (k >= a.B) continue;
-        int32_t key;
-        if (a.ids) {                                     // fused gather (first pass only): this pass reads the store records itself
-            int64_t id = a.ids[k];
-            if ((uint64_t)id >= (uint64_t)a.N) { if (a.err) atomicOr(a.err, 2); id = 0; }
-            const int4 rec = a.store[id];
-            key = col == 0 ? rec.x : rec.y;
-            if (col == 0) { a.u_out[k] = rec.x; a.i_out[k] = rec.y; a.r_out[k] = __int_as_float(rec.z); }
-        } else {
-            key = a.keys_in[col][k];
-        }
-        if (a.err && a.shift == 0) bad |= (uint32_t)key >= (uint32_t)a.limit[col];   // range check rides in the first pass
-        atomicAdd(&cnt[(key >> a.shift) & 255], 1);
+        if (!ok[r]) continue;
+        if (a.err && a.shift == 0) bad |= (uint32_t)key[r] >= (uint32_t)a.limit[col];   // range check rides in the first pass
+        atomicAdd(&cnt[(key[r] >> a.shift) & 255], 1);
     }
     if (a.err && a.shift == 0 && __any(bad) && (tid & 63) == 0) atomicOr(a.err, 1);
     __syncthreads();
