@@ -158,3 +158,45 @@ def test_fm_training_is_deterministic_and_learns():
     assert outs[0][0] == outs[1][0]                                  # bit-identical run to run
     assert np.array_equal(outs[0][1][2], outs[1][1][2])
     assert outs[0][0][-1] < 0.8 * outs[0][0][0]                      # the data loss falls
+
+
+_FM_LOAD_ROUNDS_SCRIPT = r"""
+import hashlib, os, sys
+import numpy as np
+import scipy.sparse as sp
+sys.path.insert(0, %r)
+import tfrecomm_amd as T
+opt = os.environ["TFR_TEST_OPT"]
+F, D, n, nnz = 20000, 64, 30000, 8
+rs = np.random.RandomState(7)
+with T.FmModel(F, D, loss="nll", optimizer=opt, lr=0.02 if opt == "sgd" else 0.002, reg=0.01) as m:
+    m.init(seed=3, stddev=0.05)
+    h = hashlib.sha256()
+    for s in range(3):
+        cols = np.where(rs.rand(n, nnz) < 0.3, rs.randint(0, 12, (n, nnz)), rs.randint(0, F, (n, nnz)))      # hot features
+        cols = np.sort(cols, axis=1)
+        X = sp.csr_matrix((rs.rand(n * nnz).astype(np.float32) + 0.5, cols.reshape(-1), np.arange(n + 1) * nnz), shape=(n, F))
+        y = (rs.rand(n) < 0.5).astype(np.float32)
+        pred, loss = m.train_step(X, y)
+        h.update(np.asarray(pred).tobytes()); h.update(np.float64(loss).tobytes())
+    mu, W, V = m.get()
+    h.update(np.float32(mu).tobytes()); h.update(np.ascontiguousarray(W).tobytes()); h.update(np.ascontiguousarray(V).tobytes())
+    print("HASH", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_fm_backward_three_round_load_form_is_bit_identical_to_the_general_form(optimizer):
+    """TFR_FAST=0: the FM backward through the general form of k_seg_reduce; default: the three-round form (entry records).
+    Predictions, losses, W and V after three steps on rows with hot features hash identically."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, TFR_FAST=flag, TFR_TEST_OPT=optimizer)
+        p = subprocess.run([sys.executable, "-c", _FM_LOAD_ROUNDS_SCRIPT % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        out.append([l for l in p.stdout.decode().splitlines() if l.startswith("HASH")][0])
+    assert out[0] == out[1]

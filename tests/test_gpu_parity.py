@@ -675,6 +675,64 @@ def test_two_table_form_is_bit_identical_to_the_copy_form():
     assert out[0] == out[1]
 
 
+_LOAD_ROUNDS_SCRIPT = r"""
+import hashlib, json, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import tfrecomm_amd as T
+from tfrecomm_amd import _lib as L
+c = json.loads(os.environ["TFR_TEST_CASE"])
+U, I, D, B = c["U"], c["I"], c["D"], c["B"]
+rs = np.random.RandomState(11)
+with T.SvdModel(U, I, D, **c["kw"]) as m:
+    m.init_tables(seed=5)
+    N = 4 * B
+    u = rs.randint(0, U, N).astype(np.int32)
+    i = np.where(rs.rand(N) < c["hot"], rs.randint(0, 20, N), rs.randint(0, I, N)).astype(np.int32)    # hot rows: runs cut into many pieces
+    r = (rs.randint(0, 2, N) if c["kw"].get("loss") == "nll" else rs.randint(1, 6, N)).astype(np.float32)
+    m.upload_triples(u, i, r)
+    np.random.seed(1)
+    m.rng_from_numpy()
+    loss = m.train_steps_drawn(B, 5, want_loss=True)          # look-ahead pipeline, fused steps
+    lg, l1, _ = m.train_step(u[:B - 37], i[:B - 37], r[:B - 37])          # a ragged last block
+    h = hashlib.sha256()
+    for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+        h.update(np.ascontiguousarray(m.get_table(tid)).tobytes())
+    if c["kw"]["optimizer"] == "adam":
+        for tid in (L.P | L.SLOT_M, L.P | L.SLOT_V, L.Q | L.SLOT_M, L.Q | L.SLOT_V, L.BU | L.SLOT_M, L.BI | L.SLOT_V):
+            h.update(np.ascontiguousarray(m.get_table(tid)).tobytes())
+    h.update(loss.tobytes()); h.update(lg.tobytes()); h.update(np.float32(l1).tobytes())
+    print("PLAN", m.kernel_plan(B))
+    print("HASH", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("case", [
+    dict(U=300000, I=50000, D=128, B=60000, hot=0.3, kw=dict(optimizer="adam", adam_mode="lazy", lr=2e-3, reg=0.02)),
+    dict(U=200000, I=80000, D=64, B=50000, hot=0.0, kw=dict(optimizer="sgd", lr=2e-5, reg=0.02, loss="nll", reg_bias=True)),
+    dict(U=150000, I=90000, D=16, B=70000, hot=0.5, kw=dict(optimizer="adam", adam_mode="lazy", lr=1e-3, reg=0.05, item_abs=True)),
+], ids=["adam-d128-hot", "sgd-nll-d64", "adam-abs-d16-hot"])
+def test_three_round_load_form_is_bit_identical_to_the_general_form(case):
+    """TFR_FAST=0 makes every fused launch take the general form of k_seg_reduce (loads in program order, guarded, eight
+    dependent rounds); the default takes the three-round form where it applies.  Same numbers added in the same order: tables,
+    Adam slots, losses and logits hash identically (big tables, two-table step, hot rows cut into pieces, a ragged last block)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out, plans = [], []
+    for flag in ("1", "0"):
+        env = dict(os.environ, TFR_FAST=flag, TFR_TEST_CASE=json.dumps(case))
+        p = subprocess.run([sys.executable, "-c", _LOAD_ROUNDS_SCRIPT % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        lines = p.stdout.decode().splitlines()
+        out.append([l for l in lines if l.startswith("HASH")][0])
+        plans.append([l for l in lines if l.startswith("PLAN")][0])
+    assert "true, true, true>" in plans[0] and "true, true, false>" in plans[1], plans       # the two runs did take the two forms
+    assert out[0] == out[1]
+
+
 # ------------------------------------------------------------------ BASELINE config 3 at its true size
 def test_config3_full_size_properties():
     """10M users x 1M items, dim=128, batch=262144 (5.6 GB of tables + 11 GB of Adam state, initialised
