@@ -201,7 +201,8 @@ constexpr size_t tile_step_dyn_lds(int G, int VEC, int EPG, int nbmax) {
     return (size_t)nbmax * 4 > (size_t)2 * EPG * 16 * G * VEC * 4 ? (size_t)nbmax * 4 : (size_t)2 * EPG * 16 * G * VEC * 4;
 }
 constexpr size_t seg_reduce_static_lds(int G, int VEC, bool fwd) {
-    return (size_t)1024 * VEC * 4 + (size_t)2 * (1024 / G) * 4 + (fwd ? (size_t)(2 * (1024 / G) + 1024) * 4 + 16 * 3 * 4 : 4);
+    // (an upper bound over the instantiations: the three-round item side with the forward inside also parks the own rows in LDS)
+    return (size_t)1024 * VEC * 4 + (size_t)2 * (1024 / G) * 4 + (fwd ? (size_t)(2 * (1024 / G) + 1024) * 4 + 16 * 3 * 4 + (size_t)1024 * VEC * 4 : 4);
 }
 int tile_step_epg(int ntiles, int G, int VEC);       // pieces per block k_tile_step will use (grid = ntiles * G / epg per side)
 

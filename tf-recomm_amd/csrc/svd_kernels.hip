@@ -908,8 +908,13 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     __shared__ float lds_gb[EPB];
     __shared__ int32_t lds_key[EPB];
     __shared__ float lds_stage[FWD ? 2 * EPB + 1024 : 1];
-    static_assert(sizeof(lds_t) + sizeof(lds_gb) + sizeof(lds_key) + sizeof(lds_stage) + (FWD ? 16 * 3 * 4 : 0) == seg_reduce_static_lds(G, VEC, FWD),
-                  "seg_reduce_static_lds() is out of date");
+    // FAST item side with the forward inside: the own row waits in LDS for the update after the walk (it cannot stay in
+    // registers - four of them decide whether two blocks fit a CU - and re-reading it from memory is a round trip in every
+    // block's tail and, the first read being a streaming one, 118 MB of traffic per launch at C3's shape)
+    constexpr bool OWN_LDS = FAST && FWD && LEAN && RMODE == RMODE_ADAM;
+    __shared__ float lds_o[OWN_LDS ? EPB * G * VEC : 1];
+    static_assert(sizeof(lds_t) + sizeof(lds_gb) + sizeof(lds_key) + sizeof(lds_stage) + (FWD ? 16 * 3 * 4 : 0) + (OWN_LDS ? sizeof(lds_o) : 0)
+                      <= seg_reduce_static_lds(G, VEC, FWD), "seg_reduce_static_lds() is out of date");
     const RedArgs& a = pr.a[blockIdx.y];
     const int32_t err = *a.err;
     const int grp = threadIdx.x / G;
@@ -1024,7 +1029,8 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         const ptrdiff_t palt = two_p ? a.partner_alt - a.partner : 0;
         const int ostr = a.ostride ? a.ostride : D, pstr = a.pstride ? a.pstride : D;
         xf = load_full<VEC, true>(a.partner + ((ptrdiff_t)((size_t)pidf * pstr + d0t) + ((pidw < 0) ? palt : 0)));
-        o = load_full<VEC, true>(a.own + ((ptrdiff_t)((size_t)rowc * ostr + d0t) + (cur ? oalt : 0)));
+        // (the item side's own rows are the user side's partner rows a moment later: default policy, so that they stay cached)
+        o = load_full<VEC, !OWN_LDS>(a.own + ((ptrdiff_t)((size_t)rowc * ostr + d0t) + (cur ? oalt : 0)));
         if constexpr (FWD) pbf = a.partner_bias[pidf];
         if constexpr (RMODE == RMODE_ADAM) {
             if (MV_BRANCH) {
@@ -1145,6 +1151,10 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     // contributions to LDS ([entry][G*VEC], a lane's VEC floats contiguous)
 #pragma unroll
     for (int q = 0; q < VEC; ++q) lds_t[(grp * G + gl) * VEC + q] = t.v[q];
+    if constexpr (OWN_LDS) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) lds_o[(grp * G + gl) * VEC + q] = o.v[q];
+    }
     if (gl == 0) { lds_gb[grp] = tb; lds_key[grp] = row; }
     if constexpr (FWD) {                                 // has the barrier
         if (a.stage_sum) block_sum_pieces<G, 1>(facc, lds_stage, a.partials + (size_t)blockIdx.x * 4);
@@ -1159,7 +1169,10 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     // FWD variant: the own row is re-read (an L2 hit) rather than kept live across the forward and the walk - four registers
     // that decide whether two blocks fit a CU; FAST asks for it before the walk, not after it
     Frag<VEC> wre;
-    if constexpr (FAST && FWD && LEAN && RMODE == RMODE_ADAM) wre = load_full<VEC, false>(wsrc + d0);
+    if constexpr (OWN_LDS) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) wre.v[q] = lds_o[(grp * G + gl) * VEC + q];
+    }
 
     Frag<VEC> acc = t;
     float gb = tb;
@@ -1207,7 +1220,7 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     } else if constexpr (RMODE == RMODE_ADAM) {
         if (!a.frozen_rows) {
             Frag<VEC> w;
-            if constexpr (FAST && FWD && LEAN) w = wre;
+            if constexpr (OWN_LDS) w = wre;
             else w = (FWD && LEAN) ? load_frag<VEC>(wsrc, d0, D) : o;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) adam_sparse(w.v[q], mrow.v[q], vrow.v[q], acc.v[q], c);
