@@ -1021,18 +1021,32 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         // the partner id and the selector: every row address carries it, so no row load can be scheduled ahead of the wait for
         // those two words (it hoisted the m / v loads there, and the in-order wait for the partner id then waited for both rows)
         pidf = two_p ? (pidw & 0x7fffffff) : pidw;
+        const int ostr = a.ostride ? a.ostride : D, pstr = a.pstride ? a.pstride : D;
+        // the side without a selector (user side, FM): its own row and the m / v rows need the row id only - asked for now,
+        // BEHIND the words above in issue order (compiler barriers: the in-order wait for the partner id then leaves them in
+        // flight), so only the partner row waits for the second round
+        constexpr bool EARLY = !FWD;
+        if constexpr (EARLY) {
+            asm volatile("" ::: "memory");
+            o = load_full<VEC, true>(a.own + ((size_t)rowc * ostr + d0));
+            if constexpr (RMODE == RMODE_ADAM) {
+                const size_t mvoff = (head ? roff : 0) + d0;
+                mrow = load_full<VEC, true>(a.m + mvoff);
+                vrow = load_full<VEC, true>(a.v + mvoff);
+            }
+            asm volatile("" ::: "memory");
+        }
         int32_t tok;
         asm volatile("v_mov_b32 %0, 0" : "=v"(tok) : "v"(pidw), "v"(curw));
-        cur = curw;
+        cur = EARLY ? 0 : curw;
         const int d0t = d0 + tok;
         const ptrdiff_t oalt = a.own_alt ? a.own_alt - a.own : 0;
         const ptrdiff_t palt = two_p ? a.partner_alt - a.partner : 0;
-        const int ostr = a.ostride ? a.ostride : D, pstr = a.pstride ? a.pstride : D;
         xf = load_full<VEC, true>(a.partner + ((ptrdiff_t)((size_t)pidf * pstr + d0t) + ((pidw < 0) ? palt : 0)));
         // (the item side's own rows are the user side's partner rows a moment later: default policy, so that they stay cached)
-        o = load_full<VEC, !OWN_LDS>(a.own + ((ptrdiff_t)((size_t)rowc * ostr + d0t) + (cur ? oalt : 0)));
+        if constexpr (!EARLY) o = load_full<VEC, !OWN_LDS>(a.own + ((ptrdiff_t)((size_t)rowc * ostr + d0t) + (cur ? oalt : 0)));
         if constexpr (FWD) pbf = a.partner_bias[pidf];
-        if constexpr (RMODE == RMODE_ADAM) {
+        if constexpr (RMODE == RMODE_ADAM && !EARLY) {
             if (MV_BRANCH) {
                 if (head) {
                     mrow = load_full<VEC, true>(a.m + roff + d0t);
