@@ -899,10 +899,7 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 //     partner and own rows - so a block spends one HBM latency on its rows, not three in a row.
 template <int G, int VEC, int RMODE, bool FWD = false, bool LEAN = true, bool FAST = false>
 __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
-    // FAST, where the m / v rows of non-head entries are not needed: the item side skips their loads under a branch (a fifth
-    // of its entries repeat a row: 190 -> 184 us, Zipf 146 -> 136), the user side - hardly any repeats - reads row 0 instead
-    // and stays branch-free (175.5 against 177.3 us); A/B of two builds in one call, tools/ab_mv.sh
-    constexpr bool MV_BRANCH = FWD;
+    constexpr bool MV_BRANCH = FWD;                      // FAST item side: m / v rows loaded under `if (head)` only, never merged with zeros
     constexpr int EPB = 1024 / G;
     __shared__ float lds_t[EPB * G * VEC];
     __shared__ float lds_gb[EPB];
@@ -1017,25 +1014,32 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
             mb = a.bias_m[rowh];
             vb = a.bias_v[rowh];
         }
-        // round 3: the rows, all four in one batch.  `tok` is 0, but the compiler only learns that from an instruction that reads
-        // the partner id and the selector: every row address carries it, so no row load can be scheduled ahead of the wait for
-        // those two words (it hoisted the m / v loads there, and the in-order wait for the partner id then waited for both rows)
+        // the rows.  What needs the row id only goes out now, BEHIND the words above in issue order (compiler barriers; the
+        // counter of outstanding loads retires in order, so the wait for the partner id and the selector leaves these in
+        // flight): the side without a selector (user side, FM) asks for its own row and the m / v rows, the item side for the
+        // m / v rows of run heads (a fifth of its entries repeat a row and skip them: 190 -> 184 us, Zipf 146 -> 136; the user
+        // side - hardly any repeats - reads row 0 for them and stays branch-free, 175.5 against 177.3 us).
         pidf = two_p ? (pidw & 0x7fffffff) : pidw;
         const int ostr = a.ostride ? a.ostride : D, pstr = a.pstride ? a.pstride : D;
-        // the side without a selector (user side, FM): its own row and the m / v rows need the row id only - asked for now,
-        // BEHIND the words above in issue order (compiler barriers: the in-order wait for the partner id then leaves them in
-        // flight), so only the partner row waits for the second round
         constexpr bool EARLY = !FWD;
+        asm volatile("" ::: "memory");
         if constexpr (EARLY) {
-            asm volatile("" ::: "memory");
             o = load_full<VEC, true>(a.own + ((size_t)rowc * ostr + d0));
             if constexpr (RMODE == RMODE_ADAM) {
                 const size_t mvoff = (head ? roff : 0) + d0;
                 mrow = load_full<VEC, true>(a.m + mvoff);
                 vrow = load_full<VEC, true>(a.v + mvoff);
             }
-            asm volatile("" ::: "memory");
+        } else if constexpr (RMODE == RMODE_ADAM) {
+            if (head) {
+                mrow = load_full<VEC, true>(a.m + roff + d0);
+                vrow = load_full<VEC, true>(a.v + roff + d0);
+            }
         }
+        asm volatile("" ::: "memory");
+        // last round: the partner row (and the item side's own row, whose table the selector names).  `tok` is 0, but the
+        // compiler only learns that from an instruction that reads the partner id and the selector: these addresses carry it,
+        // so the loads cannot be scheduled ahead of the wait for those two words
         int32_t tok;
         asm volatile("v_mov_b32 %0, 0" : "=v"(tok) : "v"(pidw), "v"(curw));
         cur = EARLY ? 0 : curw;
@@ -1046,18 +1050,6 @@ __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
         // (the item side's own rows are the user side's partner rows a moment later: default policy, so that they stay cached)
         if constexpr (!EARLY) o = load_full<VEC, !OWN_LDS>(a.own + ((ptrdiff_t)((size_t)rowc * ostr + d0t) + (cur ? oalt : 0)));
         if constexpr (FWD) pbf = a.partner_bias[pidf];
-        if constexpr (RMODE == RMODE_ADAM && !EARLY) {
-            if (MV_BRANCH) {
-                if (head) {
-                    mrow = load_full<VEC, true>(a.m + roff + d0t);
-                    vrow = load_full<VEC, true>(a.v + roff + d0t);
-                }
-            } else {
-                const size_t mvoff = (head ? roff : 0) + d0t;
-                mrow = load_full<VEC, true>(a.m + mvoff);
-                vrow = load_full<VEC, true>(a.v + mvoff);
-            }
-        }
     }
     if (fast_owner) {
         // loaded above
