@@ -893,10 +893,11 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 //     Both sides run fused: the item side goes first and copies each entry's pre-update Q row
 //     to own_copy_out[pos]; the user side then takes its partner rows from that copy
 //     (partner_by_pos), so neither side sees a row the other has already moved.
-//     FAST (the two-table big-table step, fused forward on the item side; launch_seg_reduce checks the conditions): the same
-//     arithmetic with the loads issued in three dependent rounds instead of eight - {sorted id, neighbour, position}, then
-//     everything the row id / position alone address (partner id, table selector, rating or g, the m / v rows, biases), then the
-//     partner and own rows - so a block spends one HBM latency on its rows, not three in a row.
+//     FAST (full-width rows; the fused big-table step, the row-sharded step's sides and owners' apply, the FM backward -
+//     launch_seg_reduce checks the conditions): the same arithmetic with the loads issued in three dependent rounds instead
+//     of eight - {sorted id, neighbour, position}, then the words the row id / position alone address (partner id, table
+//     selector, rating or g, biases) with the rows the row id alone addresses behind them (m / v, the user side's own row),
+//     then the partner row and the item side's own row - so a block spends one HBM latency on its rows, not three in a row.
 template <int G, int VEC, int RMODE, bool FWD = false, bool LEAN = true, bool FAST = false>
 __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
     constexpr bool MV_BRANCH = FWD;                      // FAST item side: m / v rows loaded under `if (head)` only, never merged with zeros
