@@ -467,6 +467,13 @@ def _sweep_cases():
     cases.append((107, 6040, 3952, 64, 10000, "adam", "tf1", "mse", False, False))
     # BASELINE configs[0] at its exact shape (the reference's CPU-runnable case): VEC=1 rows of 15 floats, one tile
     cases.append((108, 6040, 3952, 15, 1000, "adam", "tf1", "mse", False, False))
+    # big tables (radix sort + the fused kernels' three-round load form) with tiny and ragged batches: blocks that are mostly
+    # lanes past the entries; one dim that is not full-width (general form on big tables)
+    cases.append((109, 40000, 30000, 128, 1, "adam", "lazy", "mse", False, False))
+    cases.append((110, 40000, 30000, 64, 31, "sgd", "tf1", "nll", True, True))
+    cases.append((111, 70000, 20000, 16, 1057, "adam", "lazy", "mse", False, True))
+    cases.append((112, 20000, 70000, 256, 33, "adam", "lazy", "nll", True, False))
+    cases.append((113, 30000, 30000, 24, 2049, "adam", "lazy", "mse", False, False))
     return cases
 
 
