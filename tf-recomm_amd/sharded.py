@@ -64,6 +64,12 @@ def packed_stride(dim):
     return dim + 4 if dim % 4 == 0 else dim + 2
 
 
+# TFR_SHARD_ALIAS_WORLD1=1: in a one-rank world the equal-split all-to-all returns its input (RCCL would copy the buffer onto
+# itself, 150 + 140 us per step at the C3 shape) - what is left is the step's kernel time.  A measurement knob for the one-GPU
+# rehearsal, off by default: the rehearsal's point is to run the real exchanges.
+_ALIAS_WORLD1 = os.environ.get("TFR_SHARD_ALIAS_WORLD1") == "1"
+
+
 class Comm(object):
     """equal-split all-to-all / all-reduce over ``torch.distributed``.  With a CPU-only backend (gloo)
     device tensors are staged through host memory - the rehearsal path; RCCL takes them as is."""
@@ -87,6 +93,8 @@ class Comm(object):
 
     def all_to_all(self, inp, out=None):
         """``inp`` = ``world`` equal chunks along dim 0, chunk w for rank w; returns the chunks received, by source."""
+        if self.world == 1 and _ALIAS_WORLD1:
+            return inp                                   # measurement knob: a one-rank world exchanges nothing (kernel time only)
         if out is None:
             out = torch.empty_like(inp)
         if self.stage and inp.is_cuda:
@@ -100,7 +108,7 @@ class Comm(object):
     def all_to_all_start(self, inp, out=None):
         """the same exchange, started without making the caller's stream wait for it: returns (out, work); ``work.wait()`` (or
         None with the staged CPU backend, which has already finished) orders the current stream behind the exchange"""
-        if self.stage or not inp.is_cuda:
+        if self.stage or not inp.is_cuda or (self.world == 1 and _ALIAS_WORLD1):
             return self.all_to_all(inp, out), None
         if out is None:
             out = torch.empty_like(inp)
