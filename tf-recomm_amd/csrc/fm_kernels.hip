@@ -22,6 +22,7 @@ namespace tfr {
 // them round by ds_bpermute instead: no change, and slower together with NTV - not kept).
 template <int G, int VEC, bool TRAIN, bool NTV>
 __global__ __launch_bounds__(256) void k_fm_forward(FmArgs a) {
+    warm_args(a);
     constexpr int GPB = 256 / G;
     const int gl = threadIdx.x % G;
     const int d0 = gl * VEC;

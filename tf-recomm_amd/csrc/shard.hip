@@ -68,6 +68,7 @@ __device__ __forceinline__ int bucket_owner(const BucketArgs& a, int64_t k, int4
 
 // per 1024-sample block and owner: how many samples (integer LDS counters: order does not matter)
 __global__ __launch_bounds__(1024) void k_bucket_count(BucketArgs a) {
+    warm_args(a);
     extern __shared__ int32_t ocnt[];                    // [world]
     for (int w = threadIdx.x; w < a.world; w += 1024) ocnt[w] = 0;
     __syncthreads();
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void k_bucket_scan(int32_t* blk, int nblocks, 
 
 // the records, in batch order inside every owner's group
 __global__ __launch_bounds__(1024) void k_bucket_scatter(BucketArgs a) {
+    warm_args(a);
     bool bad = false, bad_id = false;
     int4 rec = make_int4(-1, -1, 0, -1);
     const int64_t k = (int64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -118,6 +120,7 @@ void launch_bucket(const BucketArgs& a, hipStream_t s) {
 
 // phase 1a: per 1024-sample block, how many samples are this rank's (and the global range check)
 __global__ __launch_bounds__(1024) void k_route_count(RouteArgs a) {
+    warm_args(a);
     bool bad = false, bad_id = false;
     int32_t u, it; float r;
     const bool f = route_mine(a, (int64_t)blockIdx.x * 1024 + threadIdx.x, &bad, &bad_id, &u, &it, &r);
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(1024) void k_route_scan(int32_t* blk, int n, int32_
 
 // phase 1b: the rank's samples, compacted in batch order; unused sample slots get keys that sort last
 __global__ __launch_bounds__(1024) void k_route_scatter(RouteArgs a) {
+    warm_args(a);
     const int64_t k = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     bool bad = false, bad_id = false;
     int32_t su = 0, sit = 0; float sr = 0.f;
@@ -179,6 +183,7 @@ __device__ __forceinline__ bool route_head(const RouteArgs& a, int64_t j, int n_
 
 // phase 2a: run heads (= distinct item ids) per block of the sorted order; distinct items per owner
 __global__ __launch_bounds__(1024) void k_route_heads(RouteArgs a) {
+    warm_args(a);
     const int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     const int n_local = a.counts[0];
     const bool h = route_head(a, j, n_local);
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(1024) void k_route_heads(RouteArgs a) {
 
 // phase 2b: slot of every local sample, the request list
 __global__ __launch_bounds__(1024) void k_route_slots(RouteArgs a) {
+    warm_args(a);
     const int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     const int n_local = a.counts[0];
     const bool h = route_head(a, j, n_local);
@@ -240,6 +246,7 @@ void launch_route_slots(const RouteArgs& a, hipStream_t s) {
 // on all of them (k_adopt_peer_err on the receiving side) - no extra collective.
 template <int G, int VEC>
 __global__ __launch_bounds__(256) void k_gather_packed(GatherPackedArgs a) {
+    warm_args(a);
     constexpr int GPB = 256 / G;
     constexpr int UN = 4;                                // requests in flight per lane group: ids in one round, rows in the next
     const int gl = threadIdx.x % G, d0 = gl * VEC;

@@ -23,6 +23,7 @@ namespace tfr {
 //   across the 16 waves of the tile: waves take turns (in order) bumping the LDS counter of
 //   their keys, so ranks follow batch order -> the sort is stable.
 __global__ __launch_bounds__(CSORT_TILE) void k_csort_rank(CSortArgs a) {
+    warm_args(a);
     extern __shared__ int32_t cnt[];
     const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const int nb = a.nbins[col];
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(1024) void k_csort_scan(ScanFinArgs sa) {
 
 // csort pass 3: scatter (key, batch position) to its sorted slot.
 __global__ __launch_bounds__(CSORT_TILE) void k_csort_scatter(CSortArgs a) {
+    warm_args(a);
     const int col = blockIdx.y, tile = blockIdx.x;
     const int64_t k = (int64_t)tile * CSORT_TILE + threadIdx.x;
     if (k >= a.B) return;
@@ -171,6 +173,7 @@ void launch_csort_tail(const CSortArgs& a, const FinArgs* fin, hipStream_t s) {
 // bin-major histogram [256][ntiles], a flat exclusive scan of it, and a scatter of (key, value).
 // Stable passes from the least significant digit up give a stable sort.
 __global__ __launch_bounds__(CSORT_TILE) void k_rsort_rank(RSortArgs a) {
+    warm_args(a);
     __shared__ int32_t cnt[256];
     const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     if (tid < 256) cnt[tid] = 0;
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(CSORT_TILE) void k_rsort_rank(RSortArgs a) {
 // each block scans its chunk locally (one coalesced int4 per thread) and publishes its total; the
 // scatter adds the totals of the preceding blocks.
 __global__ __launch_bounds__(1024) void k_rsort_scan(RSortArgs a) {
+    warm_args(a);
     __shared__ int32_t wsum[16];
     const int col = blockIdx.y, tid = threadIdx.x;
     const int32_t* __restrict__ h = a.hist[col];
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(1024) void k_rsort_scan(RSortArgs a) {
 }
 
 __global__ __launch_bounds__(CSORT_TILE) void k_rsort_scatter(RSortArgs a) {
+    warm_args(a);
     const int col = blockIdx.y, tile = blockIdx.x;
     const int64_t k = (int64_t)tile * CSORT_TILE + threadIdx.x;
     // millions of keys (FM non-zeros: 8.4 M keys = 512 scan blocks): the totals of the preceding scan blocks are
@@ -308,6 +313,7 @@ constexpr int RW_TILE = 4096;
 constexpr int RW_KPT = 4;                                // keys per thread: a wave owns 256 contiguous keys, four rounds
 
 __global__ __launch_bounds__(1024) void k_rsortw_hist(RSortArgs a) {
+    warm_args(a);
     __shared__ int32_t cnt[256];
     const int col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     if (tid < 256) cnt[tid] = 0;
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(1024) void k_rsortw_hist(RSortArgs a) {
 }
 
 __global__ __launch_bounds__(1024) void k_rsortw_scatter(RSortArgs a) {
+    warm_args(a);
     __shared__ int32_t wcnt[16][256];
     __shared__ int32_t dstart[256], gbase[256];
     __shared__ int32_t stage_k[RW_TILE], stage_v[RW_TILE];

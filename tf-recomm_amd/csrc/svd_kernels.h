@@ -34,6 +34,23 @@ struct GatherArgs {
     int32_t* u; int32_t* it; float* r; int32_t* err;
 };
 
+// Touch every 64-byte line of a kernel-argument struct with scalar loads that are all in flight together.  The compiler places
+// each argument's s_load where the argument is first used, so a latency-bound kernel pays the lines' first-touch misses one
+// after the other along its dependent chain; after this they hit the scalar cache.
+// `args` must lie inside the kernel-argument block (an array element: check the index first - reading past the block's end is
+// a page fault when the block ends a page).
+template <typename T>
+__device__ __forceinline__ void warm_args(const T& args) {
+    const char* base = reinterpret_cast<const char*>(&args);
+    constexpr int NL = (int)((sizeof(T) + 63) / 64);
+    int32_t w[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) w[k] = *reinterpret_cast<const int32_t*>(base + (k * 64 < (int)sizeof(T) - 4 ? k * 64 : (int)sizeof(T) - 4));
+#pragma unroll
+    for (int k = 0; k < NL; ++k) asm volatile("" :: "s"(w[k]));
+}
+
+
 struct RedArgs {
     const int32_t* ks; const int32_t* ps; const int32_t* other; const float* g;
     const float* own; const float* partner; const float* own_bias;

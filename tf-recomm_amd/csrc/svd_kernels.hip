@@ -370,6 +370,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a, int block, int nb
 // (tools/probes/fwd_policy.hip: 48.3 -> 46.0 us per 262144 ratings at 10M x 1M rows)
 template <int G, int VEC, int MODE, int UNR, bool PNT>
 __global__ __launch_bounds__(256) void k_forward(FwdArgs a) {
+    warm_args(a);
     forward_body<G, VEC, MODE, UNR, 4, PNT>(a, blockIdx.x, gridDim.x);
 }
 // In-LDS exclusive scan of a tile's nb bin counts into the packed form (count << 16) | start.
@@ -405,6 +406,7 @@ __device__ __forceinline__ void tile_scan_pack(int32_t* cnt, int nb, int32_t* wt
 // publish the gathered ids for the later passes.
 template <int G, int VEC>
 __global__ __launch_bounds__(1024) void k_front(FrontArgs fa) {
+    warm_args(fa);
     if ((int)blockIdx.x < fa.nfwd) {
         forward_body<G, VEC, MODE_TRAIN, 2, 16>(fa.f, blockIdx.x, fa.nfwd);
         return;
@@ -546,6 +548,7 @@ __device__ __forceinline__ void tile_sort(int32_t* cnt_, int32_t* rec_u_, int32_
 //    per-piece {loss, reg, sum g}.  EPG is chosen so that the grid stays within one block per CU.
 template <int G, int VEC, int EPG>
 __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
+    warm_args(a);
     constexpr int EPB = 1024 / G;                        // entries per piece = lane groups per block
     constexpr int EPS = EPB * EPG;                       // entries per block
     constexpr int NSL = 1024 / EPS;                      // blocks per tile
@@ -900,6 +903,8 @@ __device__ __forceinline__ void adam_sparse(float& w, float& m, float& v, float 
 //     then the partner row and the item side's own row - so a block spends one HBM latency on its rows, not three in a row.
 template <int G, int VEC, int RMODE, bool FWD = false, bool LEAN = true, bool FAST = false>
 __global__ __launch_bounds__(1024) void k_seg_reduce(RedPair pr) {
+    // (no warm_args here: thousands of workgroups per launch, the lines are in the scalar cache after the first ones - it cost
+    // the user side 172 -> 180 us and, at 64 VGPRs, the item side a block per CU)
     constexpr bool MV_BRANCH = FWD;                      // FAST item side: m / v rows loaded under `if (head)` only, never merged with zeros
     constexpr int EPB = 1024 / G;
     __shared__ float lds_t[EPB * G * VEC];
@@ -1317,6 +1322,7 @@ __device__ __forceinline__ Frag<VEC> run_total(const float* __restrict__ grad_ro
 //      owner adds the GPB partial sums in group order - a fixed order, so results stay bit-identical run to run.
 template <int G, int VEC, int OPT>
 __global__ __launch_bounds__(256) void k_apply_rows(ApplyPair pr) {
+    warm_args(pr.a[blockIdx.y]);
     constexpr int PIECE = 1024 / G;
     constexpr int GPB = 256 / G;
     constexpr int CW = 16;                               // pieces in flight per lane group in the shared walk
@@ -1459,6 +1465,7 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
         if (blockIdx.x == 0) finalize_body(pr.f);
         return;
     }
+    warm_args(pr.a[blockIdx.y]);                         // (after the y == 2 exit: pr.a has two entries)
     const DenseArgs& a = pr.a[blockIdx.y];
     if (*a.err) return;
     constexpr int GPB = 256 / G;
@@ -1542,6 +1549,7 @@ __global__ __launch_bounds__(256) void k_adam_dense(DensePair pr) {
 //      gradient buffer.  blockIdx.y == 2 runs the step's finalize (K4).
 template <int G, int VEC, bool WRITE, int NT>
 __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
+    warm_args(L.a[blockIdx.y]);
     if (blockIdx.x == gridDim.x - 1) {                   // the extra block column: K4 (optional), nothing else
         if (blockIdx.y == 0 && L.with_fin) finalize_body(L.f);
         return;
@@ -1677,7 +1685,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_finalize(FinArgs a) { finalize_body(a); }
+__global__ __launch_bounds__(256) void k_finalize(FinArgs a) { warm_args(a); finalize_body(a); }
 
 // ------------------------------------------------------------------------------------
 // AUC on the device (svd_train_val.py:97,173: sklearn's roc_auc_score(rates, sigmoid(logits)) per batch is the host
