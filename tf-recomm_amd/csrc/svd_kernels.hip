@@ -1555,8 +1555,8 @@ __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
         return;
     }
     const TileDenseArgs& a = L.a[blockIdx.y];
-    if (*a.err) return;
-    constexpr int GPB = 256 / G;
+    const int32_t err = *a.err;                          // looked at behind the first round of loads (they need no lookup table):
+    constexpr int GPB = 256 / G;                         // its round trip is then not a round of its own
     constexpr int EPB = 1024 / G;
     const int gl = threadIdx.x % G;
     const int d0 = gl * VEC;
@@ -1593,6 +1593,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(TileDenseLaunch L) {
         int32_t ent[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) ent[t] = (t < a.ntiles) ? a.tab[(size_t)t * a.nbins + row] : 0;
+        if (err) return;                                 // a voided step: the tables' contents are not to be trusted as addresses
 #pragma unroll
         for (int t0 = 0; t0 < NT; t0 += NB) {
             Frag<VEC> x[NB];
