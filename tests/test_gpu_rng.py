@@ -274,3 +274,47 @@ def test_run_ahead_between_calls_is_invisible():
             out.append((_digest(m), log))
     assert out[0][0] == out[1][0]
     assert out[0][1] == out[1][1]
+
+
+_RECS_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+import tfrecomm_amd as T
+from tfrecomm_amd import _lib as L
+U, I, D, B = 6040, 3952, 64, 10000
+rs = np.random.RandomState(5)
+with T.SvdModel(U, I, D, optimizer="adam", adam_mode="tf1", lr=1e-3, reg=0.05) as m:
+    m.init_tables(seed=7)
+    N = 300000
+    m.upload_triples(rs.randint(0, U, N).astype(np.int32), rs.randint(0, I, N).astype(np.int32), rs.randint(1, 6, N).astype(np.float32))
+    np.random.seed(3)
+    m.rng_from_numpy()
+    h = hashlib.sha256()
+    for k in (1, 7, 20, 3, 33):                      # calls of odd lengths: ids drawn ahead between calls, buffers swapped
+        h.update(m.train_steps_drawn(B, k, want_loss=True).tobytes())
+    ids = np.random.randint(0, N, (4 * B,)).astype(np.int64)      # host-staged ids in the same buffer, then drawn again
+    m.stage_ids(ids)
+    m.train_steps_staged(0, B, 4)
+    h.update(m.train_steps_drawn(B, 5, want_loss=True).tobytes())
+    for tid in (L.MU, L.BU, L.BI, L.P, L.Q):
+        h.update(np.ascontiguousarray(m.get_table(tid)).tobytes())
+    print("HASH", h.hexdigest())
+"""
+
+
+def test_records_beside_the_drawn_ids_are_invisible():
+    """TFR_RECS=0: the small-table step's sorts read ids -> store; default: the store records the drawing stream left beside
+    the ids.  Same losses and tables, bit for bit, over calls of odd lengths (ids drawn ahead, buffers swapped), host-staged
+    ids in between (no records) and drawn ids again."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, TFR_RECS=flag)
+        p = subprocess.run([sys.executable, "-c", _RECS_SCRIPT % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        out.append([l for l in p.stdout.decode().splitlines() if l.startswith("HASH")][0])
+    assert out[0] == out[1]

@@ -111,6 +111,10 @@ struct tfr_model {
     // call with the same batch size starts on ids that are already there; anything else that looks at the generator
     // first puts it back to the snapshot taken where the consumed ids end
     int64_t* d_ids_alt = nullptr; int64_t d_ids_alt_cap = 0;
+    // store records of drawn / staged ids, left beside an id buffer by the stream that filled it (one round trip instead of
+    // ids -> store for the small-table step's sorts).  Keyed by the id buffer's address, so the buffers' swaps need no care;
+    // `n` = how many leading ids of that buffer have (or will have, in stream order before their chunk's event) their records.
+    struct RecBuf { const int64_t* ids_base = nullptr; int4* recs = nullptr; int64_t cap = 0; int64_t n = 0; } rb[2];
     uint32_t* d_rng_snap = nullptr;
     bool spec_valid = false; int64_t spec_B = 0, spec_N = 0, spec_steps = 0;
     hipEvent_t spec_ev = nullptr;
@@ -435,6 +439,7 @@ int tfr_destroy(tfr_model* m) {
     for (auto e : m->chunk_ev) (void)hipEventDestroy(e);
     if (m->ev_ids_free) (void)hipEventDestroy(m->ev_ids_free);
     dfree(m->d_rng); dfree(m->d_ring); dfree(m->d_ids_alt); dfree(m->d_rng_snap);
+    dfree(m->rb[0].recs); dfree(m->rb[1].recs);
     dfree(m->rng_ws.raw); dfree(m->rng_ws.counts); dfree(m->rng_ws.hdr);
     for (auto& R : m->rt) {
         dfree(R.mine); dfree(R.u); dfree(R.it); dfree(R.r); dfree(R.slot); dfree(R.counts);
@@ -908,6 +913,49 @@ static int front_and_sort(tfr_model* m, const int32_t*& du, const int32_t*& di, 
 // resident store): was this batch's tile sort published by the previous launch?  Is there a next
 // batch to sort in this one?  The packed tables and the sorted records are double-buffered by step
 // parity (hist_* / offs_* serve as the two tables).  *par_out = which table set k_dense_tiles reads.
+// ---- record buffers (tfr_model::RecBuf) ----------------------------------------------------------------
+static bool recs_on() {                                  // TFR_RECS=0: A/B switch
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("TFR_RECS"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+static void recs_forget(tfr_model* m) { m->rb[0].n = 0; m->rb[1].n = 0; }      // the store changed / an id buffer was rewritten elsewhere
+// the record buffer that goes with the id buffer at `base` (capacity `cap` ids); a slot whose id buffer is gone is reused
+static tfr_model::RecBuf* recs_slot(tfr_model* m, const int64_t* base, int64_t cap) {
+    if (!recs_on() || !base) return nullptr;
+    tfr_model::RecBuf* r = nullptr;
+    for (int k = 0; k < 2; ++k) if (m->rb[k].ids_base == base) r = &m->rb[k];
+    if (!r) {
+        for (int k = 0; k < 2 && !r; ++k)
+            if (m->rb[k].ids_base != m->d_ids && m->rb[k].ids_base != m->d_ids_alt) r = &m->rb[k];
+        if (!r) return nullptr;
+        r->ids_base = base; r->n = 0;
+    }
+    if (r->cap < cap) {                                  // the old records' readers: the id buffer they went with was freed after a sync
+        dfree(r->recs);
+        r->recs = nullptr; r->cap = 0; r->n = 0;
+        if (hipMalloc((void**)&r->recs, (size_t)cap * sizeof(int4)) != hipSuccess) { (void)hipGetLastError(); r->ids_base = nullptr; return nullptr; }
+        r->cap = cap;
+    }
+    return r;
+}
+// after a run of ids [off, off + count) of the buffer at `base` was written on stream `st`: gather their records behind it
+static void recs_follow(tfr_model* m, const int64_t* base, int64_t cap, int64_t off, int64_t count, hipStream_t st) {
+    tfr_model::RecBuf* r = recs_slot(m, base, cap);
+    if (!r) return;
+    if (off > r->n) { r->n = 0; return; }                // a gap: nothing before `off` is known to have records
+    launch_gather_recs(base + off, m->store, r->recs + off, count, m->N, st);
+    r->n = off + count;
+}
+static const int4* recs_for(tfr_model* m, const int64_t* ids, int64_t B) {
+    if (!ids || !recs_on()) return nullptr;
+    for (int k = 0; k < 2; ++k) {
+        const tfr_model::RecBuf& r = m->rb[k];
+        if (r.recs && r.ids_base && ids >= r.ids_base && (ids - r.ids_base) + B <= r.n) return r.recs + (ids - r.ids_base);
+    }
+    return nullptr;
+}
+
 static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, const float* dr, int64_t B,
                             float* d_logits, const int64_t* d_store_ids, const int64_t* next_store_ids,
                             float* gp_rows, int* par_out, int* nblk_out) {
@@ -916,7 +964,7 @@ static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, 
     memset(&ts, 0, sizeof(ts));
     ts.P = m->w[TFR_P]; ts.Q = m->w[TFR_Q]; ts.bu = m->w[TFR_BU]; ts.bi = m->w[TFR_BI]; ts.mu = m->w[TFR_MU];
     ts.u = du; ts.it = di; ts.r = dr;
-    if (d_store_ids) { ts.ids = d_store_ids; ts.store = m->store; }
+    if (d_store_ids) { ts.ids = d_store_ids; ts.store = m->store; ts.recs = recs_for(m, d_store_ids, B); }
     ts.logits = d_logits; ts.partials = m->partials; ts.err = m->d_err;
     const bool presorted = m->pf_valid && d_store_ids && m->pf_ids == d_store_ids && m->pf_B == B;
     const int par = presorted ? m->pf_par : 0;
@@ -927,6 +975,7 @@ static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, 
     if (next_store_ids && d_store_ids) {
         ts.store = m->store;
         ts.next_ids = next_store_ids; ts.next_B = B; ts.next_ntiles = (int32_t)((B + CSORT_TILE - 1) / CSORT_TILE);
+        ts.next_recs = recs_for(m, next_store_ids, B);
         ts.next_tab[0] = tabs[par ^ 1][0]; ts.next_tab[1] = tabs[par ^ 1][1];
         ts.next_srt[0] = m->srt[par ^ 1][0]; ts.next_srt[1] = m->srt[par ^ 1][1];
         m->pf_valid = true; m->pf_ids = next_store_ids; m->pf_B = B; m->pf_par = par ^ 1;
@@ -1539,6 +1588,7 @@ static int build_store(tfr_model* m, const int32_t* u, const int32_t* i, const f
     if (m->spec_valid) { int rc0 = cancel_run_ahead(m); if (rc0) return rc0; }     // ids drawn ahead were for the old store size
     dfree(m->store);
     m->store = nullptr; m->N = 0; m->pf_valid = false;
+    recs_forget(m);
     int rc;
     if ((rc = dmalloc(&m->store, (size_t)N))) return rc;
     if (on_device) {
@@ -1621,6 +1671,7 @@ static int ensure_ids(tfr_model* m, int64_t n) {
         if ((rc = dmalloc(&m->d_ids, (size_t)want))) return rc;
         m->d_ids_cap = want;
     }
+    for (int k = 0; k < 2; ++k) if (m->rb[k].ids_base == m->d_ids) m->rb[k].n = 0;      // (a new buffer may sit at an old one's address)
     return TFR_OK;
 }
 
@@ -1632,6 +1683,7 @@ int tfr_stage_ids(tfr_model* m, const int64_t* ids, int64_t n) {
     if ((rc = ensure_ids(m, n))) return rc;
     HIPCHK(hipMemcpyAsync(m->d_ids, ids, (size_t)n * 8, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
+    for (int k = 0; k < 2; ++k) if (m->rb[k].ids_base == m->d_ids) m->rb[k].n = 0;
     m->n_ids = n;
     return TFR_OK;
 }
@@ -1742,7 +1794,10 @@ struct IdsReady {
             const int64_t s0 = first[c], s1 = first[c + 1];
             hipEvent_t pa = nullptr, pb = nullptr;
             if (m->prof && hipEventCreate(&pa) == hipSuccess && hipEventCreate(&pb) == hipSuccess) (void)hipEventRecord(pa, m->stream3);
-            if (rng != 0) launch_mt_draw(m->d_rng, m->d_ids + s0 * B, (s1 - s0) * B, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
+            if (rng != 0) {
+                launch_mt_draw(m->d_rng, m->d_ids + s0 * B, (s1 - s0) * B, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
+                recs_follow(m, m->d_ids, m->d_ids_cap, s0 * B, (s1 - s0) * B, m->stream3);
+            }
             if (pa && pb) { (void)hipEventRecord(pb, m->stream3); m->events.push_back({pa, pb, TFR_K_DRAW}); }
             if (hipGetLastError() != hipSuccess || hipEventRecord(m->chunk_ev[c], m->stream3) != hipSuccess)
                 return fail(TFR_ERR_HIP, "draw launch failed");
@@ -2079,6 +2134,7 @@ static int enqueue_run_ahead(tfr_model* m, int64_t B, int64_t nsteps, uint32_t r
         HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));  // the alternate buffer's last readers (before this call) are done
         HIPCHK(hipMemcpyAsync(m->d_rng_snap, m->d_rng, 625 * 4, hipMemcpyDeviceToDevice, m->stream3));
         launch_mt_draw(m->d_rng, m->d_ids_alt, spec * B, rng, mask_for(rng), m->stream3, nullptr, &m->rng_ws);
+        recs_follow(m, m->d_ids_alt, m->d_ids_alt_cap, 0, spec * B, m->stream3);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(m->spec_ev, m->stream3));
         m->spec_valid = true; m->spec_B = B; m->spec_N = m->N; m->spec_steps = spec;
@@ -2111,6 +2167,7 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
             HIPCHK(hipMemcpy(bigger, m->d_ids, (size_t)pre * B * 8, hipMemcpyDeviceToDevice));
             dfree(m->d_ids);
             m->d_ids = bigger; m->d_ids_cap = total;
+            recs_follow(m, m->d_ids, m->d_ids_cap, 0, pre * B, m->stream3);
         }
         HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));          // everything queued so far: the earlier calls' steps
     } else {
@@ -2122,13 +2179,17 @@ int tfr_train_steps_drawn(tfr_model* m, int64_t B, int32_t nsteps, float* loss_o
         // the draws overwrite the id buffer: they may start once every step already queued has read it
         HIPCHK(hipEventRecord(m->ev_ids_free, m->stream));
         HIPCHK(hipStreamWaitEvent(m->stream3, m->ev_ids_free, 0));
+        for (int k = 0; k < 2; ++k) if (m->rb[k].ids_base == m->d_ids) m->rb[k].n = 0;
     }
     m->pf_valid = false;                                   // the buffer's contents change: no published look-ahead sort survives
     m->n_ids = total;
     IdsReady ready;
     ready.m = m; ready.B = B; ready.nsteps = nsteps; ready.rng = rng;
     ready.plan(B >= 65536 ? 1 : (65536 / B < 16 ? 65536 / B : 16), pre);     // a chunk holds at most ~64K ids / 16 steps
-    if (rng == 0) HIPCHK(hipMemsetAsync(m->d_ids, 0, (size_t)total * 8, m->stream3));   // one-rating store: no draw consumed
+    if (rng == 0) {                                        // one-rating store: no draw consumed
+        HIPCHK(hipMemsetAsync(m->d_ids, 0, (size_t)total * 8, m->stream3));
+        for (int k = 0; k < 2; ++k) if (m->rb[k].ids_base == m->d_ids) m->rb[k].n = 0;
+    }
     tr.mark(pre ? "ids drawn ahead taken" : "no ids drawn ahead");
     if ((rc = staged_steps(m, 0, B, nsteps, loss_out, &ready))) return rc;
     tr.mark("all steps enqueued");

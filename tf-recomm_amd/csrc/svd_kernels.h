@@ -188,6 +188,7 @@ struct TileStepArgs {
     const float* P; const float* Q; const float* bu; const float* bi; const float* mu;
     const int32_t* u; const int32_t* it; const float* r;    // the batch, or (ids != NULL) rows of the store
     const int64_t* ids; const int4* store;
+    const int4* recs; const int4* next_recs;                 // optional: the (next) batch's store records, contiguous (instead of ids -> store)
     const int4* srt[2];                                      // non-NULL: this batch's tile-sorted records {u, i, r, pos},
                                                              // published by the previous step's launch (then u/it/r/ids unused)
     float* logits;                                           // optional [B]
@@ -204,6 +205,7 @@ struct TileStepArgs {
     unsigned long long* dbg;                                 // TFR_TILE_DEBUG: {start, end} of every block, 100 MHz ticks
 };
 void launch_tile_step(const TileStepArgs& a, int G, int VEC, hipStream_t s);
+void launch_gather_recs(const int64_t* ids, const void* store, void* recs, int64_t n, int64_t N, hipStream_t s);
 // LDS of k_tile_step<G, VEC, EPG>: the static arrays (the kernel static_asserts this sum against its own
 // declarations) and the dynamic request (sort bins first, then the wave-level ping-pong buffers).  A CU has 160 KB;
 // tfr_lds_bytes / tests/test_lds_budget.py enumerate every shape the dispatcher can select.

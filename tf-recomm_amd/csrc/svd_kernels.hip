@@ -480,9 +480,9 @@ struct TileLds {
     int32_t* cnt; int32_t* rec_u; int32_t* rec_i; float* rec_r; int32_t* srt_key; int32_t* srt_pos; int32_t* wtot;
 };
 __device__ __forceinline__ void tile_sort(int32_t* cnt_, int32_t* rec_u_, int32_t* rec_i_, float* rec_r_, int32_t* srt_key_,
-                                          int32_t* srt_pos_, int32_t* wtot_, const int64_t* ids, const int4* store, const int32_t* bu_,
-                                          const int32_t* bi_, const float* br_, int64_t tile0, int nvalid, int side, int nb,
-                                          int64_t N, int64_t U, int64_t I, int32_t* err) {
+                                          int32_t* srt_pos_, int32_t* wtot_, const int64_t* ids, const int4* store, const int4* recs,
+                                          const int32_t* bu_, const int32_t* bi_, const float* br_, int64_t tile0, int nvalid, int side,
+                                          int nb, int64_t N, int64_t U, int64_t I, int32_t* err) {
     TileLds L;
     L.cnt = cnt_; L.rec_u = rec_u_; L.rec_i = rec_i_; L.rec_r = rec_r_; L.srt_key = srt_key_; L.srt_pos = srt_pos_; L.wtot = wtot_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -493,7 +493,10 @@ __device__ __forceinline__ void tile_sort(int32_t* cnt_, int32_t* rec_u_, int32_
     if (valid) {
         const int64_t k = tile0 + tid;
         bool oob = false;
-        if (ids) {
+        if (recs) {                                      // the batch's store records, left beside the ids by the stream that drew
+            const int4 rec = recs[k];                    // them (api.hip RecBuf): one round trip instead of ids -> store
+            u = rec.x; it = rec.y; r = __int_as_float(rec.z);
+        } else if (ids) {
             int64_t id = ids[k];
             if ((uint64_t)id >= (uint64_t)N) { atomicOr(err, 2); id = 0; }
             const int4 rec = store[id];
@@ -584,8 +587,8 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     const bool presorted = a.srt[0] != nullptr;
     const int nb = a.nbins[side];
     if (ahead || !presorted) {
-        tile_sort(dyn, rec_u, rec_i, rec_r, srt_key, srt_pos, wtot, ahead ? a.next_ids : a.ids, a.store, a.u, a.it, a.r, tile0,
-                  nvalid, side, nb, a.N, a.U, a.I, a.err);
+        tile_sort(dyn, rec_u, rec_i, rec_r, srt_key, srt_pos, wtot, ahead ? a.next_ids : a.ids, a.store, ahead ? a.next_recs : a.recs,
+                  a.u, a.it, a.r, tile0, nvalid, side, nb, a.N, a.U, a.I, a.err);
         if (ahead) {                                     // publish the packed table and the sorted records
             for (int b = tid; b < nb; b += 1024) a.next_tab[side][(size_t)tile * nb + b] = dyn[b];
             if (tid < nvalid) {
@@ -2020,6 +2023,23 @@ void launch_init_trunc_normal(float* p, int64_t n, float stddev, uint64_t seed, 
 
 void launch_init_uniform_scalar(float* p, float lo, float hi, uint64_t seed, hipStream_t s) {
     hipLaunchKernelGGL(k_init_uniform_scalar, dim3(1), dim3(1), 0, s, p, lo, hi, seed);
+}
+
+// the store records of a run of drawn ids, left beside the ids (api.hip RecBuf; runs on the stream that drew them)
+__global__ __launch_bounds__(256) void k_gather_recs(const int64_t* __restrict__ ids, const int4* __restrict__ store, int4* __restrict__ recs,
+                                                     int64_t n, int64_t N) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        int64_t id = ids[k];
+        if ((uint64_t)id >= (uint64_t)N) id = 0;         // (drawn ids are in range by construction)
+        recs[k] = store[id];
+    }
+}
+
+void launch_gather_recs(const int64_t* ids, const void* store, void* recs, int64_t n, int64_t N, hipStream_t s) {
+    int64_t nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_gather_recs, dim3((unsigned)nb), dim3(256), 0, s, ids, reinterpret_cast<const int4*>(store), reinterpret_cast<int4*>(recs), n, N);
 }
 
 // two-table form of the big-table step: bring every row that currently lives in the alternate table back to the main
