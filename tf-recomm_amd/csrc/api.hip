@@ -1007,7 +1007,8 @@ static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, 
         for (size_t k = 0; k < h.size(); k += 8) if (h[k]) { if (h[k] < t0) t0 = h[k]; if (h[k + 1] > t1) t1 = h[k + 1]; }
         const int nsort = ts.next_ids ? 2 * ts.next_ntiles : 0;
         const size_t gridx = (size_t)nsort + (size_t)ts.ntiles * (m->G / tile_step_epg(ts.ntiles, m->G, m->VEC));
-        double ahead_end = 0, ahead_dur = 0, comp_end = 0, comp_dur = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double ahead_end = 0, ahead_dur = 0, comp_end = 0, comp_dur = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int longest_y = -1; size_t longest_k = 0;
         int nblocks = 0, ncomp = 0;
         for (size_t k = 0; k < h.size() / 8; ++k) {
             const unsigned long long* b = &h[8 * k];
@@ -1018,7 +1019,10 @@ static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, 
             if (ah) { if (en > ahead_end) ahead_end = en; if (en - st > ahead_dur) ahead_dur = en - st; }
             else {
                 if (en > comp_end) comp_end = en;
-                if (en - st > comp_dur) comp_dur = en - st;
+                if (en - st > comp_dur) {
+                    comp_dur = en - st; longest_k = k; longest_y = (int)(k / gridx);
+                    if (b[2] && b[6]) { for (int q = 2; q <= 6; ++q) phl[q] = (b[q] - b[0]) / 100.0; phl[7] = en - st; }
+                }
                 if (b[2] && b[6]) { ++ncomp; for (int q = 2; q <= 6; ++q) ph[q] += (b[q] - b[0]) / 100.0; ph[7] += en - st; }
             }
         }
@@ -1027,6 +1031,8 @@ static int tile_step_launch(tfr_model* m, const int32_t* du, const int32_t* di, 
                         "partials %.2f, wave rounds %.2f, end %.2f\n", nblocks, nsort, (t1 - t0) / 100.0, ahead_end, ahead_dur, comp_end, comp_dur,
                 ph[2] / (ncomp ? ncomp : 1), ph[3] / (ncomp ? ncomp : 1), ph[4] / (ncomp ? ncomp : 1), ph[5] / (ncomp ? ncomp : 1),
                 ph[6] / (ncomp ? ncomp : 1), ph[7] / (ncomp ? ncomp : 1));
+        fprintf(stderr, "[k_tile_step] longest step block: side %d, block %zu of its side: records %.2f, rows+contributions %.2f, wave sums staged %.2f, "
+                        "partials %.2f, wave rounds %.2f, end %.2f\n", longest_y, longest_k % gridx, phl[2], phl[3], phl[4], phl[5], phl[6], phl[7]);
     }
     return TFR_OK;
 }
