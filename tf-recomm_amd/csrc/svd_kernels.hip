@@ -552,9 +552,6 @@ __device__ __forceinline__ void tile_sort(int32_t* cnt_, int32_t* rec_u_, int32_
 template <int G, int VEC, int EPG>
 __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     warm_args(a);
-    // which side's blocks also write the logits and the per-piece {loss, reg, sum g}: the user side's - its runs rarely cross
-    // waves, so its blocks have time to spare where the item side's end the launch (per-block stamps: 7.0 against 5.0 us)
-    constexpr int FSIDE = 0;
     constexpr int EPB = 1024 / G;                        // entries per piece = lane groups per block
     constexpr int EPS = EPB * EPG;                       // entries per block
     constexpr int NSL = 1024 / EPS;                      // blocks per tile
@@ -584,7 +581,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
     const int64_t Bt = ahead ? a.next_B : a.B;
     const int nvalid = (Bt - tile0 < 1024) ? (int)(Bt - tile0) : 1024;
     if (!ahead && slice * EPS >= nvalid) {               // a short last tile: nothing in this slice
-        if (side == FSIDE && tid < 4 * EPG) a.partials[(size_t)bx * EPG * 4 + tid] = 0.f;
+        if (side == 1 && tid < 4 * EPG) a.partials[(size_t)bx * EPG * 4 + tid] = 0.f;
         return;
     }
     const bool presorted = a.srt[0] != nullptr;
@@ -715,7 +712,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
                 gk = sigmoidf_(logit) - rr[h];
                 l = fmaxf(logit, 0.f) - logit * rr[h] + log1pf(__expf(-fabsf(logit)));
             }
-            if (side == FSIDE) {
+            if (side == 1) {
                 if (gl == 0) {
                     if (a.logits) a.logits[tile0 + bpos[h]] = logit;
                     facc[3 * h + 0] = l;
@@ -781,7 +778,7 @@ __global__ __launch_bounds__(1024) void k_tile_step(TileStepArgs a, int nsort) {
         }
     }
     stamp.mark(4);                                       // wave-level sums staged
-    if (side == FSIDE) block_sum_pieces<G, EPG>(facc, lds_stage, a.partials + (size_t)bx * EPG * 4);   // has the barrier
+    if (side == 1) block_sum_pieces<G, EPG>(facc, lds_stage, a.partials + (size_t)bx * EPG * 4);   // has the barrier
     else __syncthreads();
     stamp.mark(5);
     int cur = 0;
